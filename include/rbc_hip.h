@@ -1,0 +1,137 @@
+/*
+ * rbc_hip.h -- C ABI of the MI355X-native batched Rayleigh-Benard stepper (librbc_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of MichielStraat/RBC-Gym: it replaces the
+ * Julia "plugin API" that the reference's gym envs call through juliacall
+ *   src/rbc_gym/sim/rbc_sim2D_api.jl : initialize_simulation (:17), step_simulation (:75),
+ *                                      get_state (:102), get_observation (:123),
+ *                                      get_info (:134), get_nusselt (:142)
+ * (call sites rbc2D.py:143,169,185,192,199,203-205) together with the un-vendored
+ * Oceananigans.jl v0.92.0 solver underneath it (juliapkg.json:7-10).  Differences from the
+ * reference interface, by design:
+ *   - BATCHED: one handle owns B independent env instances resident in the HBM of one GPU
+ *     (the reference holds one env in Julia module globals, one Julia runtime per env);
+ *   - opaque handle instead of module globals; integer status + rbc_last_error() instead of
+ *     Julia exceptions; nothing throws across the ABI;
+ *   - arrays are C-order [env][channel][z][x] (what rbc2D.py produces AFTER its transposes),
+ *     float32 for observations/state exactly like the Python boundary (rbc2D.py:185,192);
+ *     all solver arithmetic is float64 like the reference.
+ * Plain pointers and sizes only; no torch / HIP types in any signature (streams travel as
+ * void*).  "_dev" entry points take DEVICE pointers (zero-copy PyTorch-ROCm tensors).
+ *
+ * Threading: calls on one handle must be serialised by the caller; different handles
+ * (different GPUs) may be driven from different threads.  The library owns device state;
+ * the caller owns every I/O buffer.
+ */
+#ifndef RBC_HIP_H
+#define RBC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBC_ABI_VERSION 1
+
+/* status codes */
+enum {
+    RBC_OK = 0,
+    RBC_ERR_INVALID = 1,      /* bad argument / unsupported configuration              */
+    RBC_ERR_DEVICE = 2,       /* HIP runtime error (message in rbc_last_error)         */
+    RBC_ERR_NAN = 3,          /* at least one env produced NaNs (see rbc_get_flags)    */
+    RBC_ERR_NOT_INITIALIZED = 4 /* step/get before the first reset (rbc_sim2D_api.jl:79-81) */
+};
+
+/* Mirrors the kwargs of initialize_simulation (rbc_sim2D_api.jl:17) plus the constants it
+   hard-codes (:28-38).  Shapes are in the reference's Julia order (x, z). */
+typedef struct rbc_config {
+    int32_t abi_version;     /* = RBC_ABI_VERSION                                            */
+    int32_t dim;             /* 2 (3 reserved)                                               */
+    int32_t nx, ny, nz;      /* grid = state_shape[::-1]  (96, 1, 64)                        */
+    double  lx, ly, lz;      /* L = [2*pi, 2]                                   (api:28)     */
+    double  ra;              /* default Rayleigh number for every env            (api:17)     */
+    double  pr;              /* 0.7                                             (api:35)     */
+    double  min_b, delta_b;  /* 1, 1                                            (api:30,36)  */
+    int32_t heaters;         /* 12                                              (api:31)     */
+    double  heater_limit;    /* 0.75                                            (api:32)     */
+    double  dt_solver;       /* 0.03                                            (api:38)     */
+    double  dt_control;      /* heater_duration = 1.5                           (api:33)     */
+    double  random_kick;     /* 0.01                                            (api:37)     */
+    int32_t obs_nx, obs_nz;  /* sensors = observation_shape[::-1] (48, 8)       (api:27)     */
+    int32_t batch;           /* number of env instances B on this device                     */
+    int32_t device;          /* HIP device ordinal                                           */
+    int32_t write_state;     /* 1: rbc_step also refreshes the float32 full-state buffer     */
+} rbc_config;
+
+typedef struct rbc_handle rbc_handle;
+
+/* library / device */
+int         rbc_abi_version(void);
+const char *rbc_last_error(void);                 /* thread-local message of the last failure */
+int         rbc_device_count(void);               /* number of visible HIP devices (0 if none) */
+void        rbc_default_config(rbc_config *cfg);  /* the gym registry defaults (__init__.py:7-18) */
+
+/* lifetime: replaces gym.make()'s juliacall.newmodule + include (rbc2D.py:111-115) */
+int  rbc_create(const rbc_config *cfg, rbc_handle **out);
+int  rbc_destroy(rbc_handle *h);
+int  rbc_set_stream(rbc_handle *h, void *hip_stream);   /* NULL = the handle's own stream */
+void *rbc_get_stream(rbc_handle *h);
+int  rbc_synchronize(rbc_handle *h);
+
+/* per-env Rayleigh numbers (Ra sweep); ra[B] host pointer.  nu, kappa per api:40-41 */
+int  rbc_set_rayleigh(rbc_handle *h, const double *ra);
+
+/* initialize_simulation (api:17-70).  mask[B] (NULL = all): which envs to reset.
+   Random IC (rbc_sim2D.jl:163-171) from the library's counter-based RNG, seeds[B].        */
+int  rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds);
+/* checkpoint / identical-IC path (initialize_from_checkpoint, rbc_sim2D.jl:173-186):
+   host arrays b,u: [B][nz][nx], w: [B][nz+1][nx] float64; only masked envs are read.      */
+int  rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask,
+                           const double *b, const double *u, const double *w);
+
+/* step_simulation (api:75-97): actions [B][heaters] float32 in [-1,1] (host pointer).
+   Advances every env by dt_control. Returns RBC_OK, or RBC_ERR_NAN if any env has NaNs.   */
+int  rbc_step(rbc_handle *h, const float *actions);
+int  rbc_step_dev(rbc_handle *h, const float *actions_dev);  /* async on the handle's stream */
+
+/* get_observation (api:123-129) after rbc2D.py:191-196: [B][nch][obs_nz][obs_nx] float32,
+   channels b,u,w,(pHY',pNHS); nch = 3 or 5.                                               */
+int  rbc_get_obs(rbc_handle *h, float *out, int nch);
+/* get_state (api:102-118) after rbc2D.py:184-189: [B][nch][nz][nx] float32                */
+int  rbc_get_state(rbc_handle *h, float *out, int nch);
+/* raw float64 prognostic fields (checkpoint writer / parity tests): b,u [B][nz][nx], w [B][nz+1][nx] */
+int  rbc_get_fields(rbc_handle *h, double *b, double *u, double *w);
+/* get_nusselt (api:142-163): nu_state[B], nu_obs[B] float64 (either may be NULL)          */
+int  rbc_get_nusselt(rbc_handle *h, double *nu_state, double *nu_obs);
+/* get_info (api:134-137): t[B] float64, step[B] int64                                     */
+int  rbc_get_info(rbc_handle *h, double *t, int64_t *step);
+/* step_contains_NaNs (rbc_sim2D.jl:223-228): flags[B], 1 = NaN in b,u or w                */
+int  rbc_get_flags(rbc_handle *h, int32_t *flags);
+
+/* device-resident views for zero-copy consumers (valid until rbc_destroy):
+   obs float32 [B][5][obs_nz][obs_nx], state float32 [B][5][nz][nx],
+   nusselt float64 [B][2] (state, obs), flags int32 [B]                                    */
+void *rbc_dev_obs(rbc_handle *h);
+void *rbc_dev_state(rbc_handle *h);
+void *rbc_dev_nusselt(rbc_handle *h);
+void *rbc_dev_flags(rbc_handle *h);
+void *rbc_dev_fields(rbc_handle *h);   /* float64 [B][ b(nz*nx) | u(nz*nx) | w((nz+1)*nx) ] */
+
+/* measurement support for bench.py: HIP-event time of the step kernel(s) of the last
+   rbc_step / rbc_step_dev on the handle's stream, in milliseconds (<0 if unavailable)     */
+int    rbc_set_profiling(rbc_handle *h, int enable);
+double rbc_last_step_kernel_ms(rbc_handle *h);
+/* algorithmic HBM bytes of one env-step per env under SURVEY.md 8(d)'s convention          */
+double rbc_algorithmic_bytes_per_env_step(rbc_handle *h);
+
+/* operator-level test hooks (used by the parity tests only; not needed by the env layer):
+   tendencies G(b,u,w) of the current state for the given actions: gb,gu,gw [B][nz][nx]    */
+int  rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw);
+/* run `nsub` RK3 substeps of size dt with the given actions (no counters touched)          */
+int  rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+/*
+ * rbc_oracle.h -- CPU oracle for the 2D Rayleigh-Benard stepper.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C, fp64, one-env-at-a-time restatement of the algorithm behind the
+ * reference's env.step()/reset().  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * library (rbc-gym_amd/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned" at trajectory level.  The PDE arithmetic of the
+ * reference lives in Oceananigans.jl v0.92.0 (src/rbc_gym/juliapkg.json:7-10), which is
+ * not vendored under /root/reference and cannot be run here (no Julia, no network).
+ * The discretisation below restates that package's published algorithm (C-grid finite
+ * volume, UpwindBiased(order=5) advection with boundary-adjacent order reduction,
+ * ScalarDiffusivity, split hydrostatic pressure, Le-Moin RK3, exact FFT/eigenfunction
+ * pressure projection) and is pinned by the reference's own DATA: the 2D checkpoint
+ * files (tests/golden/ckpt2d_*.npz, ckpt2d_pins.json): discrete incompressibility, the
+ * Ra=1e4 steady attractor (residual of the restated operator on the stored states,
+ * kinetic energy, Nusselt numbers).  See DESIGN.md "Oracle".
+ */
+#ifndef RBC_ORACLE_H
+#define RBC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rbco_config {
+    int32_t nx, nz;          /* grid: x periodic, z wall-bounded (rbc_sim2D.jl:75-83)            */
+    double  lx, lz;          /* domain [2*pi, 2] (rbc_sim2D_api.jl:28)                            */
+    double  ra, pr;          /* nu = sqrt(Pr/Ra), kappa = 1/sqrt(Pr*Ra) (rbc_sim2D_api.jl:40-41)  */
+    double  min_b, delta_b;  /* top plate temperature, plate difference (api:30,36)               */
+    int32_t heaters;         /* number of bottom heater segments (12)                             */
+    double  heater_limit;    /* actuator_limit (0.75)                                             */
+    double  dt_solver;       /* 0.03 (api:38)                                                     */
+    double  dt_control;      /* heater_duration (1.5)                                             */
+    double  random_kick;     /* 0.01 (api:37)                                                     */
+    int32_t obs_nx, obs_nz;  /* sensor grid (48, 8)                                               */
+} rbco_config;
+
+/* discretisation knobs explored while pinning the restatement against the checkpoints */
+enum {
+    RBCO_VAR_BOUNDS    = 0, /* 0 (pinned): left- and right-biased stencils share ONE buffer test, the
+                                  intersection (i>=B+1)&(i<=N+1-B) [faces] / (i>=B)&(i<=N+1-B) [centres]
+                               1: separate tests per bias   2: strict i>B & i<N+1-B           */
+    RBCO_VAR_SYMLEVEL  = 1, /* 0 (pinned): advecting-velocity order follows the upwind buffer level
+                                  (Centered(4) where 5th order is allowed, else Centered(2))
+                               1: Centered(4) reduced with its own buffer test                */
+    RBCO_VAR_BUOYANCY  = 2, /* 0: split hydrostatic pressure (pHY' in G_u)  1: b in G_w         */
+    RBCO_VAR_VISCOUS   = 3, /* 0: stress-divergence form 2*nu*Sigma_ij       1: plain Laplacian  */
+    RBCO_VAR_POISSON   = 4, /* 0: FFT-x + tridiagonal-z   1: dense eigenfunction solve (DFT x DCT-II) */
+    RBCO_VAR_COUNT     = 5
+};
+
+typedef struct rbco_sim rbco_sim;
+
+rbco_sim *rbco_create(const rbco_config *cfg);
+void      rbco_destroy(rbco_sim *s);
+void      rbco_set_variant(rbco_sim *s, int which, int value);
+
+/* A3: random IC (own counter-based RNG; Julia's stream cannot be reproduced) + projection */
+void rbco_reset_random(rbco_sim *s, uint64_t seed);
+/* A14/A3: IC from arrays laid out [k][i] (b,u: nz*nx; w: (nz+1)*nx), then set!'s projection */
+void rbco_reset_from_arrays(rbco_sim *s, const double *b, const double *u, const double *w);
+/* same but WITHOUT the projection/`set!` pass (raw state load; used by operator-level tests) */
+void rbco_load_raw(rbco_sim *s, const double *b, const double *u, const double *w);
+
+/* A4: one control interval. action: `heaters` float32 values. returns 1 ok, 0 if NaN (A13) */
+int  rbco_step(rbco_sim *s, const float *action);
+/* lower-level pieces (operator-level parity tests) */
+void rbco_set_action(rbco_sim *s, const float *action);
+void rbco_update_state(rbco_sim *s);                 /* halos + pHY' + tendencies G^n          */
+void rbco_substep(rbco_sim *s, double dt);           /* one RK3 step (3 stages) of size dt      */
+void rbco_get_tendencies(const rbco_sim *s, double *gb, double *gu, double *gw); /* [k][i], gw has nz rows (faces 0..nz-1) */
+void rbco_projected_rate(rbco_sim *s, double *du, double *dw, double *db); /* d/dt after projection (steady-state residual) */
+void rbco_bottom_profile(const rbco_sim *s, double *tb);  /* nx wall temperatures (A10) */
+
+/* A11: channels [b,u,w,pHY',pNHS], each [k][i] (python order (C,z,x)); nch = 3 or 5 */
+void   rbco_get_state(const rbco_sim *s, double *out, int nch);
+void   rbco_get_state_f32(const rbco_sim *s, float *out, int nch);
+void   rbco_get_obs_f32(const rbco_sim *s, float *out, int nch);
+/* raw prognostic arrays incl. the top w face: b,u nz*nx; w (nz+1)*nx */
+void   rbco_get_fields(const rbco_sim *s, double *b, double *u, double *w);
+/* A12 */
+double rbco_nusselt(const rbco_sim *s, int on_state);
+void   rbco_get_info(const rbco_sim *s, double *t, int64_t *step);
+double rbco_max_divergence(const rbco_sim *s);
+double rbco_kinetic_energy(const rbco_sim *s);
+
+/* deterministic normal deviate shared by tests (hash of seed/field/index) */
+double rbco_normal(uint64_t seed, uint32_t field, uint32_t index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

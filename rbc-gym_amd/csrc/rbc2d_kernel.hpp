@@ -1,0 +1,817 @@
+// rbc2d_kernel.hpp -- the LDS-resident 2D Boussinesq integrator for gfx950 (MI355X).
+//
+// One workgroup owns ONE env for a whole control interval (reference: one `step_simulation`
+// call, rbc_sim2D_api.jl:75-97, i.e. n_sub RK3 substeps x 3 stages of Oceananigans'
+// NonhydrostaticModel).  The prognostic fields u, w, b of the env (3 x NZ x NX float64 =
+// 144 KiB at 64x96) stay in the CU's 160 KiB LDS from the first stage to the last; the
+// previous-stage tendencies G^- live in registers; HBM is touched only to load the state at
+// the start and to store state + observations at the end.
+//
+//   thread (i, c)  i = x index (lanes run along x -> conflict-free ds_read_b64 rows)
+//                  c = z chunk of CZ=8 cells; NX*NZ/8 = 768 threads = 12 wave64 / CU
+//
+// Per stage (what Oceananigans' time_step!/update_state! do, see DESIGN.md for file map):
+//   hydrostatic-pressure column scan -> tendencies (UpwindBiased(5) advection with
+//   boundary-adjacent order reduction, ScalarDiffusivity stress divergence) -> RK3 update in
+//   registers -> divergence -> exact Poisson solve: complex FFT-96 (8x12, two rows packed per
+//   transform) along x in LDS, tridiagonal (Thomas) solve along z per wavenumber, inverse FFT
+//   -> projection.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rbc {
+
+constexpr int CZ = 8;              // cells per thread along z
+constexpr int MAX_HEATERS = 32;
+constexpr int SCRATCH_DOUBLES = 1280;
+
+enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENCY = 3 };
+
+// Advecting-velocity reconstruction near the walls (see oracle RBCO_VAR_SYMLEVEL):
+// 0 (pinned by the reference's checkpoint ensemble, DESIGN.md "Oracle") = Centered(4) only where
+// the 5th-order upwind stencil is allowed, else Centered(2); 1 = Centered(4) with its own buffer.
+#ifndef RBC_SYMLEVEL
+#define RBC_SYMLEVEL 0
+#endif
+
+struct Params2D {
+    double *fields;            // [B][ b(NZ*NX) | u(NZ*NX) | w((NZ+1)*NX) ] float64
+    const float *actions;      // [B][heaters]
+    const double *ra;          // [B]
+    const uint8_t *mask;       // [B] or nullptr
+    const uint64_t *seeds;     // [B] (MODE_RANDOM)
+    const double *tri_inv;     // [NZ][NX/2+1] : 1/(pivot*NX) of the z tridiagonal systems
+    float *obs;                // [B][5][obs_nz][obs_nx]
+    float *state32;            // [B][5][NZ][NX]
+    double *nusselt;           // [B][2]
+    int *flags;                // [B]
+    double *dbg_g;             // [B][3][NZ][NX] (MODE_TENDENCY)
+    double lx, lz, pr, min_b, delta_b, heater_limit, kick;
+    double dt, dt_last;
+    int nsub;                  // number of RK3 substeps (the last one uses dt_last)
+    int heaters;
+    int mode;
+    int write_state;
+    int obs_nx, obs_nz;
+};
+
+// ------------------------------------------------------------------------------------------
+// counter-based normal deviates (same construction as the test oracle's rbco_normal)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ inline double normal_deviate(uint64_t seed, uint32_t field, uint32_t index)
+{
+    uint64_t ctr = ((uint64_t)field << 32) | (uint64_t)index;
+    uint64_t h0 = splitmix64(seed ^ splitmix64(ctr));
+    uint64_t r1 = splitmix64(h0 + 0x9E3779B97F4A7C15ull);
+    uint64_t r2 = splitmix64(h0 + 2 * 0x9E3779B97F4A7C15ull);
+    double u1 = (double)((r1 >> 11) + 1) * (1.0 / 9007199254740992.0);
+    double u2 = (double)(r2 >> 11) * (1.0 / 9007199254740992.0);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+// ------------------------------------------------------------------------------------------
+// reconstruction stencils (uniform grid).  a..f are six consecutive values psi[-3..+2]
+// around the target: centre->face: target face sits between c and d; face->centre alike.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double left5(double a, double b, double c, double d, double e)
+{ return (2.0 * a - 13.0 * b + 47.0 * c + 27.0 * d - 3.0 * e) * (1.0 / 60.0); }
+__device__ __forceinline__ double right5(double b, double c, double d, double e, double f)
+{ return (-3.0 * b + 27.0 * c + 47.0 * d - 13.0 * e + 2.0 * f) * (1.0 / 60.0); }
+__device__ __forceinline__ double left3(double b, double c, double d)
+{ return (-b + 5.0 * c + 2.0 * d) * (1.0 / 6.0); }
+__device__ __forceinline__ double right3(double c, double d, double e)
+{ return (2.0 * c + 5.0 * d - e) * (1.0 / 6.0); }
+__device__ __forceinline__ double sym4(double b, double c, double d, double e)
+{ return (-b + 7.0 * c + 7.0 * d - e) * (1.0 / 12.0); }
+
+// upwinded value: vel>0 takes the left-biased reconstruction (== upwind_biased_product/vel)
+__device__ __forceinline__ double upw5(double vel, double a, double b, double c, double d, double e, double f)
+{ return vel * (vel > 0.0 ? left5(a, b, c, d, e) : right5(b, c, d, e, f)); }
+
+// wall-aware version: ok5/ok3 select 5th / 3rd / 1st order (both biases share one test)
+__device__ __forceinline__ double upwz(double vel, double a, double b, double c, double d, double e, double f,
+                                        bool ok5, bool ok3)
+{
+    double L = ok5 ? left5(a, b, c, d, e) : (ok3 ? left3(b, c, d) : c);
+    double R = ok5 ? right5(b, c, d, e, f) : (ok3 ? right3(c, d, e) : d);
+    return vel * (vel > 0.0 ? L : R);
+}
+__device__ __forceinline__ double symz(double b, double c, double d, double e, bool ok4)
+{ return ok4 ? sym4(b, c, d, e) : 0.5 * (c + d); }
+
+// ------------------------------------------------------------------------------------------
+// small complex DFTs in registers (forward, e^{-i...}); inverse = call with re/im swapped
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dft8(double *re, double *im)
+{
+    const double h = 0.70710678118654752440;
+    // stage 1: pairs (j, j+4)
+    double ar[8], ai[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ar[j] = re[j] + re[j + 4]; ai[j] = im[j] + im[j + 4];
+        ar[j + 4] = re[j] - re[j + 4]; ai[j + 4] = im[j] - im[j + 4];
+    }
+    // twiddle the odd half by W8^j
+    { double t;
+      t = ar[5]; ar[5] = h * (ar[5] + ai[5]); ai[5] = h * (ai[5] - t);           // *(1-i)/sqrt2
+      t = ar[6]; ar[6] = ai[6]; ai[6] = -t;                                      // *(-i)
+      t = ar[7]; ar[7] = h * (ai[7] - ar[7]); ai[7] = -h * (t + ai[7]); }        // *(-1-i)/sqrt2
+    // two DFT-4 on (0,1,2,3) -> even outputs, (4,5,6,7) -> odd outputs
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        double *xr = ar + 4 * g, *xi = ai + 4 * g;
+        double s0r = xr[0] + xr[2], s0i = xi[0] + xi[2];
+        double d0r = xr[0] - xr[2], d0i = xi[0] - xi[2];
+        double s1r = xr[1] + xr[3], s1i = xi[1] + xi[3];
+        double d1r = xr[1] - xr[3], d1i = xi[1] - xi[3];
+        // outputs k=0..3 of the DFT-4: s0+s1, d0 - i d1, s0-s1, d0 + i d1
+        re[g + 0] = s0r + s1r; im[g + 0] = s0i + s1i;
+        re[g + 2] = d0r + d1i; im[g + 2] = d0i - d1r;
+        re[g + 4] = s0r - s1r; im[g + 4] = s0i - s1i;
+        re[g + 6] = d0r - d1i; im[g + 6] = d0i + d1r;
+    }
+}
+
+__device__ __forceinline__ void dft3(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2)
+{
+    const double s = 0.86602540378443864676;
+    double tr = r1 + r2, ti = i1 + i2;
+    double mr = r0 - 0.5 * tr, mi = i0 - 0.5 * ti;
+    double dr = s * (r1 - r2), di = s * (i1 - i2);
+    r0 += tr; i0 += ti;
+    r1 = mr + di; i1 = mi - dr;
+    r2 = mr - di; i2 = mi + dr;
+}
+
+// DFT-12 by the prime-factor (Good-Thomas) map: n=(4n1+3n2)%12, k=(4k1+9k2)%12; no twiddles
+__device__ __forceinline__ void dft12(double *re, double *im)
+{
+    double tr[3][4], ti[3][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+        double r0 = re[(3 * n2) % 12], i0 = im[(3 * n2) % 12];
+        double r1 = re[(4 + 3 * n2) % 12], i1 = im[(4 + 3 * n2) % 12];
+        double r2 = re[(8 + 3 * n2) % 12], i2 = im[(8 + 3 * n2) % 12];
+        dft3(r0, i0, r1, i1, r2, i2);
+        tr[0][n2] = r0; ti[0][n2] = i0;
+        tr[1][n2] = r1; ti[1][n2] = i1;
+        tr[2][n2] = r2; ti[2][n2] = i2;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        double s0r = tr[k1][0] + tr[k1][2], s0i = ti[k1][0] + ti[k1][2];
+        double d0r = tr[k1][0] - tr[k1][2], d0i = ti[k1][0] - ti[k1][2];
+        double s1r = tr[k1][1] + tr[k1][3], s1i = ti[k1][1] + ti[k1][3];
+        double d1r = tr[k1][1] - tr[k1][3], d1i = ti[k1][1] - ti[k1][3];
+        re[(4 * k1) % 12] = s0r + s1r;          im[(4 * k1) % 12] = s0i + s1i;
+        re[(4 * k1 + 9) % 12] = d0r + d1i;      im[(4 * k1 + 9) % 12] = d0i - d1r;
+        re[(4 * k1 + 18) % 12] = s0r - s1r;     im[(4 * k1 + 18) % 12] = s0i - s1i;
+        re[(4 * k1 + 27) % 12] = d0r - d1i;     im[(4 * k1 + 27) % 12] = d0i + d1r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int NX, int NZ>
+struct Geo {
+    static_assert(NX == 96, "x transform is an 8x12 FFT: NX must be 96");
+    static_assert(NZ % (2 * CZ) == 0, "NZ must be a multiple of 16");
+    static constexpr int NC = NZ / CZ;
+    static constexpr int NT = NX * NC;
+    static constexpr int NCELL = NX * NZ;
+    static constexpr int NH = NX / 2 + 1;                 // stored Fourier columns
+    static constexpr size_t LDS_BYTES = (size_t)(3 * NCELL + SCRATCH_DOUBLES) * sizeof(double);
+    static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
+};
+
+// position of Fourier mode m inside a transformed row (digit-reversed 8x12 order)
+__device__ __forceinline__ int mode_pos(int m) { return 12 * (m & 7) + (m >> 3); }
+
+// deterministic block reduction (sum) through LDS scratch; result broadcast to all threads
+template <int NT>
+__device__ inline double block_sum(double v, double *scr, int tid)
+{
+    __syncthreads();
+    scr[tid] = v;
+    __syncthreads();
+    if (tid < 64) {
+        double s = 0.0;
+        for (int j = tid; j < NT; j += 64) s += scr[j];
+        scr[NT + tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < 64; ++j) s += scr[NT + j];
+        scr[NT + 64] = s;
+    }
+    __syncthreads();
+    return scr[NT + 64];
+}
+
+// ------------------------------------------------------------------------------------------
+// Poisson solve + projection for one stage.  On entry un/wn hold U* of the thread's own cells
+// (w row 0 = wall = 0).  LDS U/W receive U*, Bf is scratch (rhs -> phi).  On exit un/wn and
+// LDS U/W hold the projected velocities and Bf holds phi (zero-mean NOT enforced).
+// ------------------------------------------------------------------------------------------
+template <int NX, int NZ>
+__device__ __forceinline__ void project(double *__restrict__ Us, double *__restrict__ Ws, double *__restrict__ Bf,
+                                        const double *__restrict__ tw, const double *__restrict__ tri_inv,
+                                        double (&un)[CZ], double (&wn)[CZ], double dts, double rdx, double rdz,
+                                        int tid, int i, int ip1, int im1, int k0, bool top)
+{
+    using G = Geo<NX, NZ>;
+    // publish U*
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) {
+        Us[(k0 + r) * NX + i] = un[r];
+        Ws[(k0 + r) * NX + i] = wn[r];
+    }
+    __syncthreads();
+    // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl)
+    {
+        const double rdt = 1.0 / dts;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            const int k = k0 + r;
+            double ue = Us[k * NX + ip1];
+            double wu = (r < CZ - 1) ? wn[r + 1] : (top ? 0.0 : Ws[(k + 1) * NX + i]);
+            Bf[k * NX + i] = ((ue - un[r]) * rdx + (wu - wn[r]) * rdz) * rdt;
+        }
+    }
+    __syncthreads();
+    // ---- forward FFT along x, two rows (2p, 2p+1) packed as one complex sequence ----------
+    if (tid < 12 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W96^(n2*k1)
+        const int p = tid / 12, n2 = tid - 12 * p;
+        double *R = Bf + (2 * p) * NX, *I = R + NX;
+        double re[8], im[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) { re[n1] = R[12 * n1 + n2]; im[n1] = I[12 * n1 + n2]; }
+        dft8(re, im);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) {
+            const double c = tw[2 * (n2 * 8 + k1)], s = tw[2 * (n2 * 8 + k1) + 1];  // W = c - i s
+            double t = re[k1];
+            re[k1] = t * c + im[k1] * s;
+            im[k1] = im[k1] * c - t * s;
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) { R[12 * k1 + n2] = re[k1]; I[12 * k1 + n2] = im[k1]; }
+    }
+    __syncthreads();
+    if (tid < 8 * (NZ / 2)) {           // pass B: DFT-12 over n2 for fixed k1 -> mode k1+8*k2 at 12*k1+k2
+        const int p = tid / 8, k1 = tid - 8 * p;
+        double *R = Bf + (2 * p) * NX + 12 * k1, *I = R + NX;
+        double re[12], im[12];
+#pragma unroll
+        for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
+        dft12(re, im);
+#pragma unroll
+        for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
+    }
+    __syncthreads();
+    // ---- z solve per wavenumber (Thomas); unpack / repack of the row pairing fused in ------
+    if (tid < G::NH) {
+        const int m = tid;
+        const int q1 = mode_pos(m), q2 = mode_pos((NX - m) % NX);
+        const double o = rdz * rdz, cpf = o * (double)NX;     // cp_k = o*inv_k, table holds inv_k/NX
+        double yr = 0.0, yi = 0.0;
+        for (int p = 0; p < NZ / 2; ++p) {                   // forward elimination
+            double *R = Bf + (2 * p) * NX, *I = R + NX;
+            const double r1 = R[q1], r2 = R[q2], i1 = I[q1], i2 = I[q2];
+            const double inv0 = tri_inv[(2 * p) * G::NH + m], inv1 = tri_inv[(2 * p + 1) * G::NH + m];
+            const double a_re = 0.5 * (r1 + r2), a_im = 0.5 * (i1 - i2);   // row 2p   spectrum
+            const double b_re = 0.5 * (i1 + i2), b_im = 0.5 * (r2 - r1);   // row 2p+1 spectrum
+            yr = a_re * inv0 - (inv0 * cpf) * yr;
+            yi = a_im * inv0 - (inv0 * cpf) * yi;
+            R[q1] = yr;
+            if (q1 != q2) R[q2] = yi;
+            yr = b_re * inv1 - (inv1 * cpf) * yr;
+            yi = b_im * inv1 - (inv1 * cpf) * yi;
+            I[q1] = yr;
+            if (q1 != q2) I[q2] = yi;
+        }
+        double xr = 0.0, xi = 0.0;
+        for (int p = NZ / 2 - 1; p >= 0; --p) {              // back substitution + repack
+            double *R = Bf + (2 * p) * NX, *I = R + NX;
+            const double cp1 = tri_inv[(2 * p + 1) * G::NH + m] * cpf, cp0 = tri_inv[(2 * p) * G::NH + m] * cpf;
+            double y1r = I[q1], y1i = (q1 == q2) ? 0.0 : I[q2];
+            double y0r = R[q1], y0i = (q1 == q2) ? 0.0 : R[q2];
+            const double x1r = y1r - cp1 * xr, x1i = y1i - cp1 * xi;     // row 2p+1
+            const double x0r = y0r - cp0 * x1r, x0i = y0i - cp0 * x1i;   // row 2p
+            xr = x0r; xi = x0i;
+            // Z[m] = A + iB, Z[N-m] = conj(A) + i conj(B)
+            R[q1] = x0r - x1i; I[q1] = x0i + x1r;
+            if (q1 != q2) { R[q2] = x0r + x1i; I[q2] = x1r - x0i; }
+        }
+    }
+    __syncthreads();
+    // ---- inverse FFT (swap re<->im roles) --------------------------------------------------
+    if (tid < 8 * (NZ / 2)) {
+        const int p = tid / 8, k1 = tid - 8 * p;
+        double *R = Bf + (2 * p) * NX + 12 * k1, *I = R + NX;
+        double re[12], im[12];
+#pragma unroll
+        for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
+        dft12(im, re);
+        // inverse twiddle W96^(-n2*k1): (a+ib)(c+is)
+#pragma unroll
+        for (int n2 = 1; n2 < 12; ++n2) {
+            const double c = tw[2 * (n2 * 8 + k1)], s = tw[2 * (n2 * 8 + k1) + 1];
+            double t = re[n2];
+            re[n2] = t * c - im[n2] * s;
+            im[n2] = im[n2] * c + t * s;
+        }
+#pragma unroll
+        for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
+    }
+    __syncthreads();
+    if (tid < 12 * (NZ / 2)) {
+        const int p = tid / 12, n2 = tid - 12 * p;
+        double *R = Bf + (2 * p) * NX, *I = R + NX;
+        double re[8], im[8];
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) { re[k1] = R[12 * k1 + n2]; im[k1] = I[12 * k1 + n2]; }
+        dft8(im, re);
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) { R[12 * n1 + n2] = re[n1]; I[12 * n1 + n2] = im[n1]; }
+    }
+    __syncthreads();
+    // ---- pressure_correct_velocities! ([OC] pressure_correction.jl) -------------------------
+    {
+        double pdn = (k0 > 0) ? Bf[(k0 - 1) * NX + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            const int k = k0 + r;
+            const double pc = Bf[k * NX + i], pw = Bf[k * NX + im1];
+            un[r] -= (pc - pw) * rdx * dts;
+            if (k > 0) wn[r] -= (pc - pdn) * rdz * dts;
+            pdn = pc;
+            Us[k * NX + i] = un[r];
+            Ws[k * NX + i] = wn[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+template <int NX, int NZ>
+__global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
+{
+    using G = Geo<NX, NZ>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Us = lds, *Ws = lds + G::NCELL, *Bf = lds + 2 * G::NCELL, *Sc = lds + 3 * G::NCELL;
+    double *tw = Sc;                 // [12][8][2] twiddles c,s of W96^(n2*k1) = c - i s
+    double *scr = Sc + 192;          // reductions / column-scan partials (>= NT + 65 doubles)
+
+    const int env = blockIdx.x;
+    if (P.mask && !P.mask[env]) return;
+    const int tid = threadIdx.x;
+    const int c = tid / NX, i = tid - c * NX;
+    const int k0 = c * CZ;
+    const bool bot = (c == 0), top = (c == G::NC - 1);
+    const int ip1 = (i + 1 == NX) ? 0 : i + 1, ip2 = (ip1 + 1 == NX) ? 0 : ip1 + 1, ip3 = (ip2 + 1 == NX) ? 0 : ip2 + 1;
+    const int im1 = (i == 0) ? NX - 1 : i - 1, im2 = (im1 == 0) ? NX - 1 : im1 - 1, im3 = (im2 == 0) ? NX - 1 : im2 - 1;
+
+    const double dx = P.lx / NX, dz = P.lz / NZ, rdx = 1.0 / dx, rdz = 1.0 / dz;
+    const double ra = P.ra[env];
+    const double nu = sqrt(P.pr / ra), kap = 1.0 / sqrt(P.pr * ra);   // rbc_sim2D_api.jl:40-41
+
+    if (tid < 96) {
+        const int n2 = tid / 8, k1 = tid - 8 * n2;
+        double s, cc;
+        sincospi(2.0 * (double)(n2 * k1) / (double)NX, &s, &cc);
+        tw[2 * tid] = cc; tw[2 * tid + 1] = s;
+    }
+
+    double *gf = P.fields + (size_t)env * G::ENV_STRIDE;
+    double *gb_ = gf, *gu_ = gf + G::NCELL, *gw_ = gf + 2 * G::NCELL;
+
+    // ---- A10: heater profile of this column (collate_actions_colin, rbc_sim2D.jl:87-133) ----
+    double Tb;
+    {
+        const int n = P.heaters;
+        const double ampl = P.heater_limit, hdx = 0.03;
+        const bool zero_action = (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM || P.actions == nullptr);
+        const float *act = zero_action ? nullptr : P.actions + (size_t)env * n;
+        double mean = 0.0, dev = 0.0;
+        for (int a = 0; a < n; ++a) mean += ampl * (act ? (double)act[a] : 0.0);
+        mean /= n;
+        for (int a = 0; a < n; ++a) dev = fmax(dev, fabs(ampl * (act ? (double)act[a] : 0.0) - mean));
+        double K2 = dev / ampl;
+        if (!(K2 > 1.0)) K2 = 1.0;
+        const double seg = P.lx / n, x = (i + 0.5) * dx;
+        int xs = (int)floor(x / seg) + 1;
+        if (xs > n) xs = n;
+        const int a0 = (xs == 1) ? n : xs - 1, a2 = (xs == n) ? 1 : xs + 1;
+        const double T0 = 2 + (ampl * (act ? (double)act[a0 - 1] : 0.0) - mean) / K2;
+        const double T1 = 2 + (ampl * (act ? (double)act[xs - 1] : 0.0) - mean) / K2;
+        const double T2 = 2 + (ampl * (act ? (double)act[a2 - 1] : 0.0) - mean) / K2;
+        const double xp = x - (xs - 1) * seg;
+        if (xp < hdx) Tb = T0 + ((T0 - T1) / (4 * hdx * hdx * hdx)) * (xp - 2 * hdx) * (xp + hdx) * (xp + hdx);
+        else if (xp >= seg - hdx) Tb = T1 + ((T1 - T2) / (4 * hdx * hdx * hdx)) * (xp - seg - 2 * hdx) * (xp - seg + hdx) * (xp - seg + hdx);
+        else Tb = T1;
+    }
+
+    // ---- load (or generate) the state: own cells -> registers + LDS --------------------------
+    double un[CZ], wn[CZ], bn[CZ];
+    if (P.mode == MODE_RANDOM) {   // initialize_model, rbc_sim2D.jl:163-171
+        const uint64_t seed = P.seeds[env];
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            const int k = k0 + r;
+            const uint32_t id = (uint32_t)(k * NX + i);
+            un[r] = P.kick * normal_deviate(seed, 0, id);
+            wn[r] = (k == 0) ? 0.0 : P.kick * normal_deviate(seed, 1, id);
+            const double z = (k + 0.5) * dz;
+            double v = P.min_b + (P.lz - z) * P.delta_b / 2 + P.kick * normal_deviate(seed, 2, id);
+            bn[r] = fmin(fmax(v, P.min_b), P.min_b + P.delta_b);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            const int k = k0 + r;
+            bn[r] = gb_[k * NX + i];
+            un[r] = gu_[k * NX + i];
+            wn[r] = (k == 0) ? 0.0 : gw_[k * NX + i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) {
+        Us[(k0 + r) * NX + i] = un[r];
+        Ws[(k0 + r) * NX + i] = wn[r];
+        Bf[(k0 + r) * NX + i] = bn[r];
+    }
+    __syncthreads();
+
+    double g0u[CZ], g0w[CZ], g0b[CZ];   // G^- (previous stage tendencies)
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) { g0u[r] = 0.0; g0w[r] = 0.0; g0b[r] = 0.0; }
+
+    const double hz = dz / 2;
+    const int nstage = (P.mode == MODE_STEP) ? 3 * P.nsub : ((P.mode == MODE_TENDENCY) ? 1 : 0);
+
+    if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
+        // set!'s incompressibility projection with unit time step ([OC] set_nonhydrostatic_model.jl)
+        project<NX, NZ>(Us, Ws, Bf, tw, P.tri_inv, un, wn, 1.0, rdx, rdz, tid, i, ip1, im1, k0, top);
+        // Bf holds phi (pNHS); b stays in registers
+    }
+
+    for (int st = 0; st < nstage; ++st) {
+        const int sub = st / 3, ph = st - 3 * sub;
+        const double dt = (sub == P.nsub - 1) ? P.dt_last : P.dt;
+        // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl)
+        const double gam = (ph == 0) ? 8.0 / 15.0 : (ph == 1 ? 5.0 / 12.0 : 3.0 / 4.0);
+        const double zet = (ph == 0) ? 0.0 : (ph == 1 ? -17.0 / 60.0 : -5.0 / 12.0);
+        const double dts = (gam + zet) * dt;
+
+        // ---- hydrostatic pressure anomaly: x-difference of the column integral -------------
+        // pHY'[k] = pHY'[k+1] - b_face(k+1) dz  ([OC] update_hydrostatic_pressure.jl); G_u needs
+        // (pHY'[i]-pHY'[i-1])/dx = -dz/dx * sum_{k'>=k} (dbf[k'+1]),  dbf = face mean of (b[i]-b[i-1])
+        double dphy[CZ];
+        {
+            double db[CZ + 1];
+#pragma unroll
+            for (int r = 0; r <= CZ; ++r) {
+                const int k = k0 + r;
+                if (r == CZ && top) {
+                    // top halo cell from the Value BC (both columns)
+                    const double cN = Bf[(NZ - 1) * NX + i], cM = Bf[(NZ - 1) * NX + im1];
+                    const double hN = cN + ((P.min_b - cN) / hz) * dz, hM = cM + ((P.min_b - cM) / hz) * dz;
+                    db[r] = hN - hM;
+                } else {
+                    db[r] = Bf[k * NX + i] - Bf[k * NX + im1];
+                }
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int r = CZ - 1; r >= 0; --r) { acc += 0.5 * (db[r] + db[r + 1]); dphy[r] = acc; }
+            scr[c * NX + i] = acc;
+            __syncthreads();
+            double above = 0.0;
+            for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) dphy[r] = -(dphy[r] + above) * dz;   // = pHY'[i,k]-pHY'[i-1,k]
+        }
+
+        double gn[CZ];
+        // ======================= b tendency =====================================================
+        {
+            // rolling column window of b around the face above the current cell
+            double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 relative to face k (face between w2,w3)
+            auto brow = [&](int k) -> double { return Bf[min(max(k, 0), NZ - 1) * NX + i]; };
+            w0 = brow(k0 - 3); w1 = brow(k0 - 2); w2 = brow(k0 - 1); w3 = brow(k0); w4 = brow(k0 + 1); w5 = brow(k0 + 2);
+            // flux through the bottom face of the chunk (face k0); wall -> 0
+            double fz_lo;
+            {
+                const double wv = Ws[k0 * NX + i];
+                fz_lo = bot ? 0.0 : upwz(wv, w0, w1, w2, w3, w4, w5, true, true);
+            }
+            // halo value below the first cell (diffusion)
+            double bdn = bot ? (w3 + ((w3 - Tb) / hz) * (-dz)) : w2;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                // slide window up by one: now centred on face k+1
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = brow(k + 3);
+                const double b0 = w2;
+                const double *row = Bf + k * NX;
+                const double bm3 = row[im3], bm2 = row[im2], bm1 = row[im1], bp1 = row[ip1], bp2 = row[ip2], bp3 = row[ip3];
+                const double ui = Us[k * NX + i], ue = Us[k * NX + ip1];
+                const double fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
+                const double fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
+                // face k+1 (1-based face index k+2): 5th if 3<=k+1<=NZ-3, 3rd if 2<=k+1<=NZ-2
+                double fz_hi, bup;
+                if (r == CZ - 1 && top) {
+                    fz_hi = 0.0;
+                    bup = b0 + ((P.min_b - b0) / hz) * dz;
+                } else {
+                    const double wv = Ws[(k + 1) * NX + i];
+                    const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
+                    const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
+                    fz_hi = upwz(wv, w0, w1, w2, w3, w4, w5, ok5, ok3);
+                    bup = w3;
+                }
+                const double adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
+                const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * (rdx * rdx) + ((bup - b0) - (b0 - bdn)) * (rdz * rdz));
+                gn[r] = dif - adv;
+                fz_lo = fz_hi;
+                bdn = b0;
+            }
+        }
+        if (P.mode == MODE_TENDENCY) {
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) P.dbg_g[((size_t)env * 3 + 0) * G::NCELL + (k0 + r) * NX + i] = gn[r];
+        }
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            bn[r] += dt * (gam * gn[r] + zet * g0b[r]);
+            g0b[r] = gn[r];
+        }
+        // ======================= u tendency =====================================================
+        {
+            auto urow = [&](int k) -> double { return Us[min(max(k, 0), NZ - 1) * NX + i]; };
+            double w0, w1, w2, w3, w4, w5;
+            w0 = urow(k0 - 3); w1 = urow(k0 - 2); w2 = urow(k0 - 1); w3 = urow(k0); w4 = urow(k0 + 1); w5 = urow(k0 + 2);
+            // z-face k0: advecting w interpolated in x to the u column (Centered(4), periodic)
+            double wm_lo = Ws[k0 * NX + im1], wc_lo = Ws[k0 * NX + i];   // w[i-1], w[i] at face k (viscous cross term)
+            double fz_lo;
+            {
+                const double wt = sym4(Ws[k0 * NX + im2], wm_lo, wc_lo, Ws[k0 * NX + ip1]);
+                fz_lo = bot ? 0.0 : upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
+            }
+            double udn = bot ? (w3 + ((w3 - 0.0) / hz) * (-dz)) : w2;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = urow(k + 3);
+                const double u0 = w2;
+                const double *row = Us + k * NX;
+                const double um3 = row[im3], um2 = row[im2], um1 = row[im1], up1 = row[ip1], up2 = row[ip2], up3 = row[ip3];
+                // flux_uu at centres i-1 and i  (advective_momentum_flux_Uu)
+                const double ut_w = sym4(um2, um1, u0, up1);          // centre i-1: faces i-2..i+1
+                const double ut_e = sym4(um1, u0, up1, up2);          // centre i
+                const double fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
+                const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
+                double fz_hi, uup, wm_hi, wc_hi;
+                if (r == CZ - 1 && top) {
+                    fz_hi = 0.0; wm_hi = 0.0; wc_hi = 0.0;
+                    uup = u0 + ((0.0 - u0) / hz) * dz;
+                } else {
+                    const double *wr = Ws + (k + 1) * NX;
+                    wm_hi = wr[im1]; wc_hi = wr[i];
+                    const double wt = sym4(wr[im2], wm_hi, wc_hi, wr[ip1]);
+                    const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
+                    const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
+                    fz_hi = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
+                    uup = w3;
+                }
+                const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures isotropic ScalarDiffusivity)
+                const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * (rdx * rdx)
+                                         + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
+                gn[r] = vis - adv - dphy[r] * rdx;
+                fz_lo = fz_hi; udn = u0; wm_lo = wm_hi; wc_lo = wc_hi;
+            }
+        }
+        if (P.mode == MODE_TENDENCY) {
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) P.dbg_g[((size_t)env * 3 + 1) * G::NCELL + (k0 + r) * NX + i] = gn[r];
+        }
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            un[r] += dt * (gam * gn[r] + zet * g0u[r]);
+            g0u[r] = gn[r];
+        }
+        // ======================= w tendency (faces k0..k0+7; wall face 0 never evolves) ========
+        {
+            auto wrow = [&](int k) -> double { return (k >= NZ) ? 0.0 : Ws[min(max(k, 0), NZ - 1) * NX + i]; };
+            auto urw = [&](int k, int col) -> double { return Us[min(max(k, 0), NZ - 1) * NX + col]; };
+            // w column window: faces k-2..k+3 around centre k (between faces k, k+1)
+            double w0, w1, w2, w3, w4, w5;
+            // start around centre k0-1: faces k0-3..k0+2
+            w0 = wrow(k0 - 3); w1 = wrow(k0 - 2); w2 = wrow(k0 - 1); w3 = wrow(k0); w4 = wrow(k0 + 1); w5 = wrow(k0 + 2);
+            // flux_ww at centre k0-1 (1-based centre index k0): 5th if 2<=kc<=NZ-3, 3rd if 1<=kc<=NZ-2
+            double fz_lo = 0.0;
+            if (!bot) {
+                const double wt = symz(w1, w2, w3, w4, true);
+                fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
+            }
+            // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
+            double a0 = urw(k0 - 2, i), a1 = urw(k0 - 1, i), a2 = urw(k0, i), a3 = urw(k0 + 1, i);
+            double e0 = urw(k0 - 2, ip1), e1 = urw(k0 - 1, ip1), e2 = urw(k0, ip1), e3 = urw(k0 + 1, ip1);
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;          // z-face k, and centre k above it
+                if (r > 0) {
+                    a0 = a1; a1 = a2; a2 = a3; a3 = urw(k + 1, i);
+                    e0 = e1; e1 = e2; e2 = e3; e3 = urw(k + 1, ip1);
+                }
+                // slide w window to centre k: faces k-2..k+3
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = wrow(k + 3);
+                const double wc = w2;          // w at face k
+                // flux_ww at centre k (0-based): 5th if 2<=k<=NZ-3, 3rd if 1<=k<=NZ-2, else 1st
+                const bool c5 = ((r >= 2) || !bot) && ((r <= CZ - 3) || !top);
+                const bool c3 = ((r >= 1) || !bot) && ((r <= CZ - 2) || !top);
+#if RBC_SYMLEVEL
+                const bool c4 = c3;            // Centered(4) own buffer: 1<=k<=NZ-2
+#else
+                const bool c4 = c5;
+#endif
+                const double wt = symz(w1, w2, w3, w4, c4);
+                const double fz_hi = upwz(wt, w0, w1, w2, w3, w4, w5, c5, c3);
+                if (bot && r == 0) { gn[r] = 0.0; fz_lo = fz_hi; continue; }
+                // flux_uw at (x-face i, z-face k) and (x-face i+1, z-face k)
+#if RBC_SYMLEVEL
+                const bool f4 = ((r >= 2) || !bot);                    // 2<=k<=NZ-2 (k<=NZ-1 always here... top face NZ excluded)
+                const bool f4t = f4 && ((r <= CZ - 2) || !top);
+#else
+                const bool f4t = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
+#endif
+                const double ut_w = symz(a0, a1, a2, a3, f4t);
+                const double ut_e = symz(e0, e1, e2, e3, f4t);
+                const double *row = Ws + k * NX;
+                const double wm3 = row[im3], wm2 = row[im2], wm1 = row[im1], wp1 = row[ip1], wp2 = row[ip2], wp3 = row[ip3];
+                const double fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
+                const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
+                const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
+                                         + 2.0 * ((w3 - wc) - (wc - w1)) * (rdz * rdz));
+                gn[r] = vis - adv;
+                fz_lo = fz_hi;
+            }
+        }
+        if (P.mode == MODE_TENDENCY) {
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) P.dbg_g[((size_t)env * 3 + 2) * G::NCELL + (k0 + r) * NX + i] = gn[r];
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            wn[r] += dt * (gam * gn[r] + zet * g0w[r]);
+            g0w[r] = gn[r];
+        }
+        __syncthreads();   // every read of the old state is done
+        project<NX, NZ>(Us, Ws, Bf, tw, P.tri_inv, un, wn, dts, rdx, rdz, tid, i, ip1, im1, k0, top);
+        if (st + 1 < nstage) {
+            __syncthreads();   // phi reads done -> Bf takes the new b
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) Bf[(k0 + r) * NX + i] = bn[r];
+            __syncthreads();
+        }
+    }
+
+    // =========================== outputs ========================================================
+    // here: un, wn, bn = final own-cell values; LDS U, W = final u, w; Bf = phi of the last stage
+    __syncthreads();
+    // state back to HBM
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) {
+        const int k = k0 + r;
+        gb_[k * NX + i] = bn[r];
+        gu_[k * NX + i] = un[r];
+        gw_[k * NX + i] = wn[r];
+    }
+    if (top) gw_[NZ * NX + i] = 0.0;
+
+    // A13 NaN flag
+    double bad = 0.0;
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) bad += (isnan(bn[r]) || isnan(un[r]) || isnan(wn[r])) ? 1.0 : 0.0;
+    bad = block_sum<G::NT>(bad, scr, tid);
+    if (tid == 0) P.flags[env] = (bad > 0.0) ? 1 : 0;
+
+    // pNHS = phi - mean(phi)   (the reference solver zeroes the mean mode)
+    double ph[CZ];
+    double psum = 0.0;
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) { ph[r] = Bf[(k0 + r) * NX + i]; psum += ph[r]; }
+    psum = block_sum<G::NT>(psum, scr, tid);
+    const double pmean = psum / (double)G::NCELL;
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) ph[r] -= pmean;
+
+    // pHY' (absolute) by the same column scan; Bf (free now) takes the final b
+    double phy[CZ];
+    {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) Bf[(k0 + r) * NX + i] = bn[r];
+        __syncthreads();
+        const double babove = top ? (bn[CZ - 1] + ((P.min_b - bn[CZ - 1]) / hz) * dz) : Bf[(k0 + CZ) * NX + i];
+        double acc = 0.0;
+#pragma unroll
+        for (int r = CZ - 1; r >= 0; --r) {
+            const double bup = (r == CZ - 1) ? babove : bn[r + 1];
+            acc += 0.5 * (bn[r] + bup);
+            phy[r] = acc;
+        }
+        scr[c * NX + i] = acc;
+        __syncthreads();
+        double above = 0.0;
+        for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) phy[r] = -(phy[r] + above) * dz;
+    }
+    // now LDS: U=u, W=w, Bf=b (final)
+
+    // A11 observation / state (float32, channel order b,u,w,pHY',pNHS; layout [c][z][x])
+    {
+        const int stx = NX / P.obs_nx, stz = NZ / P.obs_nz;
+        float *ob = P.obs + (size_t)env * 5 * P.obs_nz * P.obs_nx;
+        const size_t och = (size_t)P.obs_nz * P.obs_nx;
+        const bool xs = (i % stx) == 0;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) {
+            const int k = k0 + r;
+            if (xs && (k % stz) == 0) {
+                const size_t o = (size_t)(k / stz) * P.obs_nx + (i / stx);
+                ob[o] = (float)bn[r]; ob[och + o] = (float)un[r]; ob[2 * och + o] = (float)wn[r];
+                ob[3 * och + o] = (float)phy[r]; ob[4 * och + o] = (float)ph[r];
+            }
+        }
+        if (P.write_state) {
+            float *sb = P.state32 + (size_t)env * 5 * G::NCELL;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int o = (k0 + r) * NX + i;
+                sb[o] = (float)bn[r]; sb[G::NCELL + o] = (float)un[r]; sb[2 * G::NCELL + o] = (float)wn[r];
+                sb[3 * G::NCELL + o] = (float)phy[r]; sb[4 * G::NCELL + o] = (float)ph[r];
+            }
+        }
+    }
+
+    // A12 Nusselt numbers (get_nusselt rbc_sim2D_api.jl:142-163, array_gradient rbc_sim2D.jl:206-220)
+    for (int which = 0; which < 2; ++which) {   // 0: full state, 1: sensor grid
+        const int stx = which ? NX / P.obs_nx : 1, stz = which ? NZ / P.obs_nz : 1;
+        const int mx = NX / stx, mz = NZ / stz;
+        double q1 = 0.0;
+        const bool xs = (i % stx) == 0;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r)
+            if (xs && ((k0 + r) % stz) == 0) q1 += bn[r] * wn[r];
+        q1 = block_sum<G::NT>(q1, scr, tid);
+        // row means of T on the (sub)grid: thread t sums segment seg of row
+        __syncthreads();
+        {
+            const int row = tid / 12, seg = tid - 12 * row;   // NT = 12*NZ threads: NX/8 = 12 segments per row
+            double s = 0.0;
+            if ((row % stz) == 0)
+                for (int j = 0; j < 8; ++j) { const int x = 8 * seg + j; if ((x % stx) == 0) s += Bf[row * NX + x]; }
+            scr[tid] = s;
+        }
+        __syncthreads();
+        if (tid < NZ) {
+            double s = 0.0;
+            for (int j = 0; j < 12; ++j) s += scr[tid * 12 + j];
+            scr[G::NT + 66 + tid] = s / (double)mx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double *tx = scr + G::NT + 66;
+            double g = 0.0;
+            for (int kk = 0; kk < mz; ++kk) {
+                const double cur = tx[kk * stz];
+                if (kk == 0) g += tx[stz] - cur;
+                else if (kk == mz - 1) g += cur - tx[(kk - 1) * stz];
+                else g += (tx[(kk + 1) * stz] - tx[(kk - 1) * stz]) / 2;
+            }
+            const double q2 = kap * (g / mz);
+            const double q1m = q1 / ((double)mx * mz);
+            P.nusselt[(size_t)env * 2 + which] = (q1m - q2) / (kap * P.delta_b / P.lz);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace rbc
