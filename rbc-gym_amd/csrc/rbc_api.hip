@@ -1,0 +1,543 @@
+// rbc_api.hip -- host side of librbc_hip.so: the C ABI declared in include/rbc_hip.h.
+//
+// Replaces the reference's Julia plugin API (src/rbc_gym/sim/rbc_sim2D_api.jl) for a BATCH of
+// envs resident on one MI355X.  All PDE work happens in rbc2d_kernel (rbc2d_kernel.hpp); this
+// file only owns device buffers, the per-env clocks (api:12-13,67-68,87-88) and the launches.
+// There is deliberately no CPU fallback: every entry point that needs the GPU fails with
+// RBC_ERR_DEVICE when HIP does.
+#include "rbc2d_kernel.hpp"
+
+#include "../../include/rbc_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RBC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+}  // namespace
+
+struct rbc_handle {
+    rbc_config cfg;
+    int B = 0, nx = 0, nz = 0;
+    size_t ncell = 0, env_stride = 0, obs_sz = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    double *d_fields = nullptr, *d_ra = nullptr, *d_tri = nullptr, *d_nu = nullptr, *d_dbg = nullptr;
+    float *d_actions = nullptr, *d_obs = nullptr, *d_state = nullptr;
+    uint8_t *d_mask = nullptr;
+    uint64_t *d_seeds = nullptr;
+    int *d_flags = nullptr;
+    std::vector<double> t;
+    std::vector<int64_t> step;
+    std::vector<uint8_t> inited;
+    std::vector<double> stage;        // host staging for reset_from_arrays
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;
+    double last_ms = -1.0;
+    int nsub = 0;
+    double dt_last = 0.0;
+    void (*kernel)(const rbc::Params2D) = nullptr;
+    size_t lds_bytes = 0;
+    int threads = 0;
+};
+
+namespace {
+
+template <int NX, int NZ>
+void bind_kernel(rbc_handle *h)
+{
+    h->kernel = rbc::rbc2d_kernel<NX, NZ>;
+    h->lds_bytes = rbc::Geo<NX, NZ>::LDS_BYTES;
+    h->threads = rbc::Geo<NX, NZ>::NT;
+}
+
+// LU pivots of the z-direction operator of every Fourier mode (pressure solve):
+//   (phi[k-1] - 2 phi[k] + phi[k+1])/dz^2 - lam_x(m) phi[k] = r[k], mirror (Neumann) ends.
+// Stored as 1/(pivot*NX) so the unnormalised forward+inverse FFT pair needs no extra scaling.
+std::vector<double> tri_table(int nx, int nz, double lx, double lz)
+{
+    const int nh = nx / 2 + 1;
+    const double dx = lx / nx, dz = lz / nz, o = 1.0 / (dz * dz), pi = 3.14159265358979323846;
+    std::vector<double> tab((size_t)nz * nh);
+    for (int m = 0; m < nh; ++m) {
+        const double s = 2.0 * std::sin(m * pi / nx) / dx, lam = s * s;   // poisson_eigenvalues, Periodic
+        double piv = 0.0;
+        for (int k = 0; k < nz; ++k) {
+            double d = -((k == 0 || k == nz - 1) ? 1.0 : 2.0) * o - lam;
+            if (m == 0 && k == nz - 1) d -= o;   // pin the singular mean mode (mean removed on output)
+            piv = (k == 0) ? d : d - o * o / piv;
+            tab[(size_t)k * nh + m] = 1.0 / (piv * nx);
+        }
+    }
+    return tab;
+}
+
+rbc::Params2D base_params(const rbc_handle *h)
+{
+    rbc::Params2D p{};
+    p.fields = h->d_fields;
+    p.actions = nullptr;
+    p.ra = h->d_ra;
+    p.mask = nullptr;
+    p.seeds = h->d_seeds;
+    p.tri_inv = h->d_tri;
+    p.obs = h->d_obs;
+    p.state32 = h->d_state;
+    p.nusselt = h->d_nu;
+    p.flags = h->d_flags;
+    p.dbg_g = h->d_dbg;
+    p.lx = h->cfg.lx; p.lz = h->cfg.lz; p.pr = h->cfg.pr;
+    p.min_b = h->cfg.min_b; p.delta_b = h->cfg.delta_b;
+    p.heater_limit = h->cfg.heater_limit; p.kick = h->cfg.random_kick;
+    p.dt = h->cfg.dt_solver; p.dt_last = h->dt_last; p.nsub = h->nsub;
+    p.heaters = h->cfg.heaters;
+    p.mode = rbc::MODE_STEP;
+    p.write_state = h->cfg.write_state;
+    p.obs_nx = h->cfg.obs_nx; p.obs_nz = h->cfg.obs_nz;
+    return p;
+}
+
+int launch(rbc_handle *h, const rbc::Params2D &p, bool timed)
+{
+    if (timed && h->profiling) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, p);
+    HIP_TRY(hipGetLastError());
+    if (timed && h->profiling) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    return RBC_OK;
+}
+
+int check_handle(const rbc_handle *h)
+{
+    if (!h) return fail(RBC_ERR_INVALID, "null handle");
+    return RBC_OK;
+}
+
+int all_initialized(const rbc_handle *h)
+{
+    for (int e = 0; e < h->B; ++e)
+        if (!h->inited[e])
+            return fail(RBC_ERR_NOT_INITIALIZED, "Simulation not initialized. Call rbc_reset first.");   // api:79-81
+    return RBC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbc_abi_version(void) { return RBC_ABI_VERSION; }
+
+const char *rbc_last_error(void) { return g_err.c_str(); }
+
+int rbc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rbc_default_config(rbc_config *c)
+{
+    // gym registry defaults, src/rbc_gym/__init__.py:7-18, + constants rbc_sim2D_api.jl:28-38
+    std::memset(c, 0, sizeof(*c));
+    c->abi_version = RBC_ABI_VERSION;
+    c->dim = 2;
+    c->nx = 96; c->ny = 1; c->nz = 64;
+    c->lx = 2.0 * 3.14159265358979323846; c->ly = 1.0; c->lz = 2.0;
+    c->ra = 1e4; c->pr = 0.7;
+    c->min_b = 1.0; c->delta_b = 1.0;
+    c->heaters = 12; c->heater_limit = 0.75;
+    c->dt_solver = 0.03; c->dt_control = 1.5;
+    c->random_kick = 0.01;
+    c->obs_nx = 48; c->obs_nz = 8;
+    c->batch = 1; c->device = 0; c->write_state = 1;
+}
+
+int rbc_create(const rbc_config *cfg, rbc_handle **out)
+{
+    if (!cfg || !out) return fail(RBC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != RBC_ABI_VERSION) return fail(RBC_ERR_INVALID, "rbc_config.abi_version mismatch");
+    if (cfg->dim != 2) return fail(RBC_ERR_INVALID, "only dim=2 is implemented in this build");
+    if (cfg->batch < 1) return fail(RBC_ERR_INVALID, "batch must be >= 1");
+    if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
+    if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
+        return fail(RBC_ERR_INVALID, "ra, pr, dt_solver, dt_control must be positive");
+    if (cfg->obs_nx < 1 || cfg->obs_nz < 2 || cfg->nx % cfg->obs_nx || cfg->nz % cfg->obs_nz)
+        return fail(RBC_ERR_INVALID, "sensor grid must divide the state grid (and have >= 2 rows)");
+
+    auto *h = new rbc_handle();
+    h->cfg = *cfg;
+    h->B = cfg->batch; h->nx = cfg->nx; h->nz = cfg->nz;
+    if (cfg->nx == 96 && cfg->nz == 64) bind_kernel<96, 64>(h);
+    else if (cfg->nx == 96 && cfg->nz == 48) bind_kernel<96, 48>(h);
+    else if (cfg->nx == 96 && cfg->nz == 32) bind_kernel<96, 32>(h);
+    else {
+        delete h;
+        return fail(RBC_ERR_INVALID, "unsupported grid: the LDS-resident 2D kernel is built for nx=96, nz in {32,48,64}");
+    }
+    h->ncell = (size_t)h->nx * h->nz;
+    h->env_stride = (size_t)(3 * h->nz + 1) * h->nx;
+    h->obs_sz = (size_t)cfg->obs_nx * cfg->obs_nz;
+    {
+        const double T = cfg->dt_control, dt = cfg->dt_solver;
+        int nfull = (int)std::floor(T / dt + 1e-9);
+        double rem = T - nfull * dt;
+        if (rem > 1e-9 * dt) { h->nsub = nfull + 1; h->dt_last = rem; }
+        else { h->nsub = nfull; h->dt_last = dt; }
+        if (h->nsub < 1) { delete h; return fail(RBC_ERR_INVALID, "dt_control shorter than one solver step"); }
+    }
+
+#define CREATE_TRY(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            int rc_ = fail(RBC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+            rbc_destroy(h);                                                                        \
+            return rc_;                                                                            \
+        }                                                                                          \
+    } while (0)
+
+    int ndev = 0;
+    CREATE_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) { delete h; return fail(RBC_ERR_DEVICE, "no such HIP device"); }
+    CREATE_TRY(hipSetDevice(cfg->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    const size_t B = h->B;
+    CREATE_TRY(hipMalloc(&h->d_fields, B * h->env_stride * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_fields, 0, B * h->env_stride * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_ra, B * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_actions, B * cfg->heaters * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->d_mask, B));
+    CREATE_TRY(hipMalloc(&h->d_seeds, B * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc(&h->d_obs, B * 5 * h->obs_sz * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->d_state, B * 5 * h->ncell * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->d_nu, B * 2 * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_flags, B * sizeof(int)));
+    CREATE_TRY(hipMemset(h->d_flags, 0, B * sizeof(int)));
+    {
+        std::vector<double> tab = tri_table(h->nx, h->nz, cfg->lx, cfg->lz);
+        CREATE_TRY(hipMalloc(&h->d_tri, tab.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(h->d_tri, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> ra(B, cfg->ra);
+        CREATE_TRY(hipMemcpy(h->d_ra, ra.data(), B * sizeof(double), hipMemcpyHostToDevice));
+    }
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes));
+#undef CREATE_TRY
+    h->t.assign(B, 0.0);
+    h->step.assign(B, 1);
+    h->inited.assign(B, 0);
+    *out = h;
+    return RBC_OK;
+}
+
+int rbc_destroy(rbc_handle *h)
+{
+    if (!h) return RBC_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_actions, h->d_obs, h->d_state,
+                    h->d_mask, h->d_seeds, h->d_flags};
+    for (void *b : bufs)
+        if (b) hipFree(b);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return RBC_OK;
+}
+
+int rbc_set_stream(rbc_handle *h, void *hip_stream)
+{
+    if (int rc = check_handle(h)) return rc;
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return RBC_OK;
+}
+
+void *rbc_get_stream(rbc_handle *h) { return h ? reinterpret_cast<void *>(h->stream) : nullptr; }
+
+int rbc_synchronize(rbc_handle *h)
+{
+    if (int rc = check_handle(h)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RBC_OK;
+}
+
+int rbc_set_rayleigh(rbc_handle *h, const double *ra)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!ra) return fail(RBC_ERR_INVALID, "null ra");
+    for (int e = 0; e < h->B; ++e)
+        if (!(ra[e] > 0)) return fail(RBC_ERR_INVALID, "Rayleigh numbers must be positive");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->d_ra, ra, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
+    return RBC_OK;
+}
+
+static int upload_mask(rbc_handle *h, const uint8_t *mask, std::vector<uint8_t> &m)
+{
+    m.assign(h->B, 1);
+    if (mask)
+        for (int e = 0; e < h->B; ++e) m[e] = mask[e] ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(h->d_mask, m.data(), h->B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RBC_OK;
+}
+
+static void mark_reset(rbc_handle *h, const std::vector<uint8_t> &m)
+{
+    for (int e = 0; e < h->B; ++e)
+        if (m[e]) {
+            h->t[e] = 0.0;      // api:68
+            h->step[e] = 1;     // api:67
+            h->inited[e] = 1;
+        }
+}
+
+int rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!seeds) return fail(RBC_ERR_INVALID, "null seeds");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<uint8_t> m;
+    if (int rc = upload_mask(h, mask, m)) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    rbc::Params2D p = base_params(h);
+    p.mode = rbc::MODE_RANDOM;
+    p.mask = h->d_mask;
+    if (int rc = launch(h, p, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    mark_reset(h, m);
+    return RBC_OK;
+}
+
+int rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask, const double *b, const double *u, const double *w)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!b || !u || !w) return fail(RBC_ERR_INVALID, "null field array");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<uint8_t> m;
+    if (int rc = upload_mask(h, mask, m)) return rc;
+    const size_t nc = h->ncell, nw = nc + h->nx;
+    h->stage.resize(h->env_stride);
+    for (int e = 0; e < h->B; ++e) {
+        if (!m[e]) continue;
+        std::memcpy(h->stage.data(), b + (size_t)e * nc, nc * sizeof(double));
+        std::memcpy(h->stage.data() + nc, u + (size_t)e * nc, nc * sizeof(double));
+        std::memcpy(h->stage.data() + 2 * nc, w + (size_t)e * nw, nw * sizeof(double));
+        HIP_TRY(hipMemcpy(h->d_fields + (size_t)e * h->env_stride, h->stage.data(), h->env_stride * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+    rbc::Params2D p = base_params(h);
+    p.mode = rbc::MODE_PROJECT;
+    p.mask = h->d_mask;
+    if (int rc = launch(h, p, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    mark_reset(h, m);
+    return RBC_OK;
+}
+
+static void advance_clocks(rbc_handle *h)
+{
+    for (int e = 0; e < h->B; ++e) {
+        h->t[e] += h->cfg.dt_control;   // api:87
+        h->step[e] += 1;                // api:88
+    }
+}
+
+int rbc_step_dev(rbc_handle *h, const float *actions_dev)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = all_initialized(h)) return rc;
+    if (!actions_dev) return fail(RBC_ERR_INVALID, "null actions");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    rbc::Params2D p = base_params(h);
+    p.actions = actions_dev;
+    if (int rc = launch(h, p, true)) return rc;
+    advance_clocks(h);
+    return RBC_OK;
+}
+
+int rbc_step(rbc_handle *h, const float *actions)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = all_initialized(h)) return rc;
+    if (!actions) return fail(RBC_ERR_INVALID, "null actions");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpyAsync(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice,
+                           h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // `actions` may be pageable: do not return before it is consumed
+    if (int rc = rbc_step_dev(h, h->d_actions)) return rc;
+    std::vector<int32_t> fl(h->B);
+    HIP_TRY(hipMemcpyAsync(fl.data(), h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int e = 0; e < h->B; ++e)
+        if (fl[e]) return fail(RBC_ERR_NAN, "Error in simulation step, probably NaN values");   // rbc2D.py:171
+    return RBC_OK;
+}
+
+static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t chan, int nch)
+{
+    if (!out) return fail(RBC_ERR_INVALID, "null output");
+    if (nch < 1 || nch > 5) return fail(RBC_ERR_INVALID, "nch must be in 1..5");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy2D(out, (size_t)nch * chan * sizeof(float), dev, 5 * chan * sizeof(float),
+                        (size_t)nch * chan * sizeof(float), h->B, hipMemcpyDeviceToHost));
+    return RBC_OK;
+}
+
+int rbc_get_obs(rbc_handle *h, float *out, int nch)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = all_initialized(h)) return rc;
+    return copy_channels(h, out, h->d_obs, h->obs_sz, nch);
+}
+
+int rbc_get_state(rbc_handle *h, float *out, int nch)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = all_initialized(h)) return rc;
+    if (!h->cfg.write_state) return fail(RBC_ERR_INVALID, "handle was created with write_state=0");
+    return copy_channels(h, out, h->d_state, h->ncell, nch);
+}
+
+int rbc_get_fields(rbc_handle *h, double *b, double *u, double *w)
+{
+    if (int rc = check_handle(h)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t nc = h->ncell, nw = nc + h->nx, pitch = h->env_stride * sizeof(double);
+    if (b) HIP_TRY(hipMemcpy2D(b, nc * sizeof(double), h->d_fields, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    if (u) HIP_TRY(hipMemcpy2D(u, nc * sizeof(double), h->d_fields + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    if (w) HIP_TRY(hipMemcpy2D(w, nw * sizeof(double), h->d_fields + 2 * nc, pitch, nw * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    return RBC_OK;
+}
+
+int rbc_get_nusselt(rbc_handle *h, double *nu_state, double *nu_obs)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = all_initialized(h)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<double> tmp((size_t)h->B * 2);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_nu, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int e = 0; e < h->B; ++e) {
+        if (nu_state) nu_state[e] = tmp[2 * e];
+        if (nu_obs) nu_obs[e] = tmp[2 * e + 1];
+    }
+    return RBC_OK;
+}
+
+int rbc_get_info(rbc_handle *h, double *t, int64_t *step)
+{
+    if (int rc = check_handle(h)) return rc;
+    for (int e = 0; e < h->B; ++e) {
+        if (t) t[e] = h->t[e];
+        if (step) step[e] = h->step[e];
+    }
+    return RBC_OK;
+}
+
+int rbc_get_flags(rbc_handle *h, int32_t *flags)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!flags) return fail(RBC_ERR_INVALID, "null flags");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpyAsync(flags, h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RBC_OK;
+}
+
+void *rbc_dev_obs(rbc_handle *h) { return h ? h->d_obs : nullptr; }
+void *rbc_dev_state(rbc_handle *h) { return h ? h->d_state : nullptr; }
+void *rbc_dev_nusselt(rbc_handle *h) { return h ? h->d_nu : nullptr; }
+void *rbc_dev_flags(rbc_handle *h) { return h ? h->d_flags : nullptr; }
+void *rbc_dev_fields(rbc_handle *h) { return h ? h->d_fields : nullptr; }
+
+int rbc_set_profiling(rbc_handle *h, int enable)
+{
+    if (int rc = check_handle(h)) return rc;
+    h->profiling = enable != 0;
+    h->last_ms = -1.0;
+    return RBC_OK;
+}
+
+double rbc_last_step_kernel_ms(rbc_handle *h)
+{
+    if (!h || !h->profiling) return -1.0;
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+double rbc_algorithmic_bytes_per_env_step(rbc_handle *h)
+{
+    if (!h) return 0.0;
+    // B_sub = 10 * F * C * s (F=3 prognostic fields, C cells, s=8 bytes) per RK3 substep
+    return (double)h->nsub * 10.0 * 3.0 * (double)h->ncell * 8.0;
+}
+
+int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!actions || !gb || !gu || !gw) return fail(RBC_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t nc = h->ncell;
+    if (!h->d_dbg) HIP_TRY(hipMalloc(&h->d_dbg, (size_t)h->B * 3 * nc * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice));
+    rbc::Params2D p = base_params(h);
+    p.mode = rbc::MODE_TENDENCY;
+    p.actions = h->d_actions;
+    p.nsub = 1;
+    if (int rc = launch(h, p, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t pitch = 3 * nc * sizeof(double);
+    HIP_TRY(hipMemcpy2D(gb, nc * sizeof(double), h->d_dbg, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(gu, nc * sizeof(double), h->d_dbg + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(gw, nc * sizeof(double), h->d_dbg + 2 * nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    return RBC_OK;
+}
+
+int rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!actions || nsub < 1 || !(dt > 0)) return fail(RBC_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice));
+    rbc::Params2D p = base_params(h);
+    p.actions = h->d_actions;
+    p.nsub = nsub;
+    p.dt = dt;
+    p.dt_last = dt;
+    if (int rc = launch(h, p, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RBC_OK;
+}
+
+}  // extern "C"

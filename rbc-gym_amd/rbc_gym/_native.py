@@ -1,0 +1,245 @@
+"""ctypes binding of librbc_hip.so (the C ABI in include/rbc_hip.h).
+
+This is the Python side of the drop-in boundary: where the reference does
+``juliacall.newmodule("RBCGymAPI")`` + ``include("rbc_sim2D_api.jl")`` (rbc2D.py:111-115),
+this package loads one shared library.  There is no fallback: if the library is missing or
+no MI355X is visible, constructing a simulation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)                      # rbc-gym_amd/
+LIB_PATH = os.path.join(ROOT, "lib", "librbc_hip.so")
+
+RBC_OK, RBC_ERR_INVALID, RBC_ERR_DEVICE, RBC_ERR_NAN, RBC_ERR_NOT_INITIALIZED = range(5)
+ABI_VERSION = 1
+
+
+class RbcConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("dim", C.c_int32),
+                ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("lx", C.c_double), ("ly", C.c_double), ("lz", C.c_double),
+                ("ra", C.c_double), ("pr", C.c_double),
+                ("min_b", C.c_double), ("delta_b", C.c_double),
+                ("heaters", C.c_int32), ("heater_limit", C.c_double),
+                ("dt_solver", C.c_double), ("dt_control", C.c_double),
+                ("random_kick", C.c_double),
+                ("obs_nx", C.c_int32), ("obs_nz", C.c_int32),
+                ("batch", C.c_int32), ("device", C.c_int32), ("write_state", C.c_int32)]
+
+
+# every symbol include/rbc_hip.h declares: name -> (restype, argtypes)
+_vp, _dp, _fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
+_u8p, _u64p, _i64p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+SYMBOLS = {
+    "rbc_abi_version": (C.c_int, []),
+    "rbc_last_error": (C.c_char_p, []),
+    "rbc_device_count": (C.c_int, []),
+    "rbc_default_config": (None, [C.POINTER(RbcConfig)]),
+    "rbc_create": (C.c_int, [C.POINTER(RbcConfig), C.POINTER(_vp)]),
+    "rbc_destroy": (C.c_int, [_vp]),
+    "rbc_set_stream": (C.c_int, [_vp, _vp]),
+    "rbc_get_stream": (_vp, [_vp]),
+    "rbc_synchronize": (C.c_int, [_vp]),
+    "rbc_set_rayleigh": (C.c_int, [_vp, _dp]),
+    "rbc_reset": (C.c_int, [_vp, _u8p, _u64p]),
+    "rbc_reset_from_arrays": (C.c_int, [_vp, _u8p, _dp, _dp, _dp]),
+    "rbc_step": (C.c_int, [_vp, _fp]),
+    "rbc_step_dev": (C.c_int, [_vp, _vp]),
+    "rbc_get_obs": (C.c_int, [_vp, _fp, C.c_int]),
+    "rbc_get_state": (C.c_int, [_vp, _fp, C.c_int]),
+    "rbc_get_fields": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "rbc_get_nusselt": (C.c_int, [_vp, _dp, _dp]),
+    "rbc_get_info": (C.c_int, [_vp, _dp, _i64p]),
+    "rbc_get_flags": (C.c_int, [_vp, _i32p]),
+    "rbc_dev_obs": (_vp, [_vp]),
+    "rbc_dev_state": (_vp, [_vp]),
+    "rbc_dev_nusselt": (_vp, [_vp]),
+    "rbc_dev_flags": (_vp, [_vp]),
+    "rbc_dev_fields": (_vp, [_vp]),
+    "rbc_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "rbc_last_step_kernel_ms": (C.c_double, [_vp]),
+    "rbc_algorithmic_bytes_per_env_step": (C.c_double, [_vp]),
+    "rbc_debug_tendencies": (C.c_int, [_vp, _fp, _dp, _dp, _dp]),
+    "rbc_debug_substeps": (C.c_int, [_vp, _fp, C.c_int, C.c_double]),
+}
+
+_lib = None
+
+
+class RbcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def load_library(path=None):
+    """Load librbc_hip.so and bind every declared symbol.  Raises if the library is absent:
+    the product path never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("RBC_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise ImportError(
+            f"librbc_hip.so not found at {p}: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). rbc_gym has no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rbc_abi_version() != ABI_VERSION:
+        raise ImportError("librbc_hip.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def default_config():
+    cfg = RbcConfig()
+    load_library().rbc_default_config(C.byref(cfg))
+    return cfg
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+class NativeSim:
+    """A batch of B envs on one GPU.  Method names follow the reference's Julia API
+    (rbc_sim2D_api.jl): initialize_simulation -> reset*, step_simulation -> step, get_state,
+    get_observation, get_info, get_nusselt."""
+
+    def __init__(self, batch=1, device=0, **kw):
+        self.lib = load_library()
+        cfg = default_config()
+        cfg.batch, cfg.device = int(batch), int(device)
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown config field {k}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = _vp()
+        self._check(self.lib.rbc_create(C.byref(cfg), C.byref(self.h)))
+        self.B, self.nx, self.nz = cfg.batch, cfg.nx, cfg.nz
+        self.obs_shape = (cfg.obs_nz, cfg.obs_nx)
+        self.heaters = cfg.heaters
+
+    def _check(self, rc):
+        if rc != RBC_OK:
+            raise RbcError(rc, self.lib.rbc_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rbc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- initialize_simulation ---------------------------------------------------------------
+    def _mask(self, mask):
+        if mask is None:
+            return None, None
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (self.B,)
+        return m, _ptr(m, _u8p)
+
+    def reset(self, seeds, mask=None):
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.B,)))
+        m, mp = self._mask(mask)
+        self._check(self.lib.rbc_reset(self.h, mp, _ptr(s, _u64p)))
+
+    def reset_from_arrays(self, b, u, w, mask=None):
+        b = np.ascontiguousarray(b, np.float64); u = np.ascontiguousarray(u, np.float64); w = np.ascontiguousarray(w, np.float64)
+        assert b.shape == (self.B, self.nz, self.nx) and u.shape == b.shape and w.shape == (self.B, self.nz + 1, self.nx)
+        m, mp = self._mask(mask)
+        self._check(self.lib.rbc_reset_from_arrays(self.h, mp, _ptr(b, _dp), _ptr(u, _dp), _ptr(w, _dp)))
+
+    def set_rayleigh(self, ra):
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(ra, np.float64), (self.B,)))
+        self._check(self.lib.rbc_set_rayleigh(self.h, _ptr(r, _dp)))
+
+    # -- step_simulation ---------------------------------------------------------------------
+    def _actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.B, self.heaters):
+            raise ValueError(f"actions must have shape {(self.B, self.heaters)}, got {a.shape}")
+        return a
+
+    def step(self, actions):
+        a = self._actions(actions)
+        rc = self.lib.rbc_step(self.h, _ptr(a, _fp))
+        if rc == RBC_ERR_NAN:
+            return False
+        self._check(rc)
+        return True
+
+    def step_dev(self, actions_dev_ptr):
+        self._check(self.lib.rbc_step_dev(self.h, _vp(actions_dev_ptr)))
+
+    # -- getters -----------------------------------------------------------------------------
+    def get_obs(self, nch=3):
+        o = np.empty((self.B, nch) + self.obs_shape, np.float32)
+        self._check(self.lib.rbc_get_obs(self.h, _ptr(o, _fp), nch))
+        return o
+
+    def get_state(self, nch=3):
+        o = np.empty((self.B, nch, self.nz, self.nx), np.float32)
+        self._check(self.lib.rbc_get_state(self.h, _ptr(o, _fp), nch))
+        return o
+
+    def get_fields(self):
+        b = np.empty((self.B, self.nz, self.nx)); u = np.empty_like(b); w = np.empty((self.B, self.nz + 1, self.nx))
+        self._check(self.lib.rbc_get_fields(self.h, _ptr(b, _dp), _ptr(u, _dp), _ptr(w, _dp)))
+        return b, u, w
+
+    def get_nusselt(self):
+        a = np.empty(self.B); o = np.empty(self.B)
+        self._check(self.lib.rbc_get_nusselt(self.h, _ptr(a, _dp), _ptr(o, _dp)))
+        return a, o
+
+    def get_info(self):
+        t = np.empty(self.B); s = np.empty(self.B, np.int64)
+        self._check(self.lib.rbc_get_info(self.h, _ptr(t, _dp), _ptr(s, _i64p)))
+        return t, s
+
+    def get_flags(self):
+        f = np.empty(self.B, np.int32)
+        self._check(self.lib.rbc_get_flags(self.h, _ptr(f, _i32p)))
+        return f
+
+    def synchronize(self):
+        self._check(self.lib.rbc_synchronize(self.h))
+
+    # -- measurement / test hooks --------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._check(self.lib.rbc_set_profiling(self.h, 1 if on else 0))
+
+    def last_step_kernel_ms(self):
+        return self.lib.rbc_last_step_kernel_ms(self.h)
+
+    def algorithmic_bytes_per_env_step(self):
+        return self.lib.rbc_algorithmic_bytes_per_env_step(self.h)
+
+    def debug_tendencies(self, actions):
+        a = self._actions(actions)
+        g = [np.empty((self.B, self.nz, self.nx)) for _ in range(3)]
+        self._check(self.lib.rbc_debug_tendencies(self.h, _ptr(a, _fp), _ptr(g[0], _dp), _ptr(g[1], _dp), _ptr(g[2], _dp)))
+        return dict(b=g[0], u=g[1], w=g[2])
+
+    def debug_substeps(self, actions, nsub, dt):
+        a = self._actions(actions)
+        self._check(self.lib.rbc_debug_substeps(self.h, _ptr(a, _fp), int(nsub), float(dt)))
+
+    def dev_ptrs(self):
+        L = self.lib
+        return dict(obs=L.rbc_dev_obs(self.h), state=L.rbc_dev_state(self.h), nusselt=L.rbc_dev_nusselt(self.h),
+                    flags=L.rbc_dev_flags(self.h), fields=L.rbc_dev_fields(self.h))
