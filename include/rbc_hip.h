@@ -118,10 +118,12 @@ void *rbc_dev_nusselt(rbc_handle *h);
 void *rbc_dev_flags(rbc_handle *h);
 void *rbc_dev_fields(rbc_handle *h);   /* float64 [B][ b(nz*nx) | u(nz*nx) | w((nz+1)*nx) ] */
 
-/* measurement support for bench.py: HIP-event time of the step kernel(s) of the last
-   rbc_step / rbc_step_dev on the handle's stream, in milliseconds (<0 if unavailable)     */
-int    rbc_set_profiling(rbc_handle *h, int enable);
-double rbc_last_step_kernel_ms(rbc_handle *h);
+/* measurement support for bench.py: HIP events are recorded on the handle's stream around
+   every step-kernel launch of rbc_step / rbc_step_dev (up to max_launches launches between
+   two reads; 0 disables).  rbc_profile_read waits for the recorded launches, writes their
+   durations in milliseconds to ms[0..capacity) and returns how many it wrote (-1 on error). */
+int    rbc_set_profiling(rbc_handle *h, int max_launches);
+int    rbc_profile_read(rbc_handle *h, double *ms, int capacity);
 /* algorithmic HBM bytes of one env-step per env under SURVEY.md 8(d)'s convention          */
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h);
 

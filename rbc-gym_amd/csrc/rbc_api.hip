@@ -48,9 +48,9 @@ struct rbc_handle {
     std::vector<int64_t> step;
     std::vector<uint8_t> inited;
     std::vector<double> stage;        // host staging for reset_from_arrays
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev;       // profiling: (start, stop) pairs, one pair per timed launch
+    size_t ev_used = 0;               // pairs recorded since the last rbc_profile_read
     bool profiling = false;
-    double last_ms = -1.0;
     int nsub = 0;
     double dt_last = 0.0;
     void (*kernel)(const rbc::Params2D) = nullptr;
@@ -116,10 +116,14 @@ rbc::Params2D base_params(const rbc_handle *h)
 
 int launch(rbc_handle *h, const rbc::Params2D &p, bool timed)
 {
-    if (timed && h->profiling) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
+    if (rec) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
     hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, p);
     HIP_TRY(hipGetLastError());
-    if (timed && h->profiling) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    if (rec) {
+        HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
+        h->ev_used++;
+    }
     return RBC_OK;
 }
 
@@ -220,8 +224,6 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    CREATE_TRY(hipEventCreate(&h->ev0));
-    CREATE_TRY(hipEventCreate(&h->ev1));
     const size_t B = h->B;
     CREATE_TRY(hipMalloc(&h->d_fields, B * h->env_stride * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_fields, 0, B * h->env_stride * sizeof(double)));
@@ -254,15 +256,14 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
 int rbc_destroy(rbc_handle *h)
 {
     if (!h) return RBC_OK;
-    hipSetDevice(h->cfg.device);
-    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    (void)hipSetDevice(h->cfg.device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_actions, h->d_obs, h->d_state,
                     h->d_mask, h->d_seeds, h->d_flags};
     for (void *b : bufs)
-        if (b) hipFree(b);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+        if (b) (void)hipFree(b);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return RBC_OK;
 }
@@ -478,22 +479,35 @@ void *rbc_dev_nusselt(rbc_handle *h) { return h ? h->d_nu : nullptr; }
 void *rbc_dev_flags(rbc_handle *h) { return h ? h->d_flags : nullptr; }
 void *rbc_dev_fields(rbc_handle *h) { return h ? h->d_fields : nullptr; }
 
-int rbc_set_profiling(rbc_handle *h, int enable)
+int rbc_set_profiling(rbc_handle *h, int max_launches)
 {
     if (int rc = check_handle(h)) return rc;
-    h->profiling = enable != 0;
-    h->last_ms = -1.0;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->ev_used = 0;
+    h->profiling = max_launches > 0;
+    for (int n = 0; n < 2 * max_launches; ++n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
     return RBC_OK;
 }
 
-double rbc_last_step_kernel_ms(rbc_handle *h)
+int rbc_profile_read(rbc_handle *h, double *ms, int capacity)
 {
-    if (!h || !h->profiling) return -1.0;
-    if (hipSetDevice(h->cfg.device) != hipSuccess) return -1.0;
-    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
-    float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
-    return (double)ms;
+    if (!h || !ms) return -1;
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return -1;
+    int n = 0;
+    for (size_t j = 0; j < h->ev_used && n < capacity; ++j, ++n) {
+        float v = -1.0f;
+        if (hipEventSynchronize(h->ev[2 * j + 1]) != hipSuccess) return -1;
+        if (hipEventElapsedTime(&v, h->ev[2 * j], h->ev[2 * j + 1]) != hipSuccess) return -1;
+        ms[n] = (double)v;
+    }
+    h->ev_used = 0;
+    return n;
 }
 
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h)

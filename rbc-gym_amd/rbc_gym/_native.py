@@ -61,7 +61,7 @@ SYMBOLS = {
     "rbc_dev_flags": (_vp, [_vp]),
     "rbc_dev_fields": (_vp, [_vp]),
     "rbc_set_profiling": (C.c_int, [_vp, C.c_int]),
-    "rbc_last_step_kernel_ms": (C.c_double, [_vp]),
+    "rbc_profile_read": (C.c_int, [_vp, _dp, C.c_int]),
     "rbc_algorithmic_bytes_per_env_step": (C.c_double, [_vp]),
     "rbc_debug_tendencies": (C.c_int, [_vp, _fp, _dp, _dp, _dp]),
     "rbc_debug_substeps": (C.c_int, [_vp, _fp, C.c_int, C.c_double]),
@@ -220,11 +220,15 @@ class NativeSim:
         self._check(self.lib.rbc_synchronize(self.h))
 
     # -- measurement / test hooks --------------------------------------------------------------
-    def set_profiling(self, on=True):
-        self._check(self.lib.rbc_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, max_launches):
+        self._check(self.lib.rbc_set_profiling(self.h, int(max_launches)))
 
-    def last_step_kernel_ms(self):
-        return self.lib.rbc_last_step_kernel_ms(self.h)
+    def profile_read(self, capacity=4096):
+        ms = np.empty(capacity)
+        n = self.lib.rbc_profile_read(self.h, _ptr(ms, _dp), capacity)
+        if n < 0:
+            raise RbcError(RBC_ERR_DEVICE, "rbc_profile_read failed")
+        return ms[:n].copy()
 
     def algorithmic_bytes_per_env_step(self):
         return self.lib.rbc_algorithmic_bytes_per_env_step(self.h)
