@@ -181,6 +181,11 @@ __device__ __forceinline__ void dft12(double *re, double *im)
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS layout: rows interleave the three fields, F(k, f, i) = lds[(3k + f) * NX + i] with
+// f = 0:u 1:w 2:b (the b slot doubles as the Poisson right-hand side / potential).  One
+// address VGPR per stencil column then reaches every field and row through the 16-bit
+// immediate offset of ds_read_b64.
+// ------------------------------------------------------------------------------------------
 template <int NX, int NZ>
 struct Geo {
     static_assert(NX == 96, "x transform is an 8x12 FFT: NX must be 96");
@@ -189,6 +194,8 @@ struct Geo {
     static constexpr int NT = NX * NC;
     static constexpr int NCELL = NX * NZ;
     static constexpr int NH = NX / 2 + 1;                 // stored Fourier columns
+    static constexpr int RS = 3 * NX;                     // LDS row stride (doubles)
+    static constexpr int FU = 0, FW = NX, FB = 2 * NX;    // field offsets inside a row
     static constexpr size_t LDS_BYTES = (size_t)(3 * NCELL + SCRATCH_DOUBLES) * sizeof(double);
     static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
 };
@@ -219,40 +226,39 @@ __device__ inline double block_sum(double v, double *scr, int tid)
 }
 
 // ------------------------------------------------------------------------------------------
-// Poisson solve + projection for one stage.  On entry un/wn hold U* of the thread's own cells
-// (w row 0 = wall = 0).  LDS U/W receive U*, Bf is scratch (rhs -> phi).  On exit un/wn and
-// LDS U/W hold the projected velocities and Bf holds phi (zero-mean NOT enforced).
+// Poisson solve + projection for one stage.  On entry the u,w slots of the thread's own cells
+// hold U* (written by the caller, not yet fenced); the b slot is scratch (rhs -> phi).  On exit
+// u,w hold the projected velocities (own cells written, not fenced) and the b slot holds phi
+// (its mean is NOT removed).
 // ------------------------------------------------------------------------------------------
 template <int NX, int NZ>
-__device__ __forceinline__ void project(double *__restrict__ Us, double *__restrict__ Ws, double *__restrict__ Bf,
-                                        const double *__restrict__ tw, const double *__restrict__ tri_inv,
-                                        double (&un)[CZ], double (&wn)[CZ], double dts, double rdx, double rdz,
+__device__ __forceinline__ void project(double *__restrict__ lds, const double *__restrict__ tw,
+                                        const double *__restrict__ tri_inv, double dts, double rdx, double rdz,
                                         int tid, int i, int ip1, int im1, int k0, bool top)
 {
     using G = Geo<NX, NZ>;
-    // publish U*
-#pragma unroll
-    for (int r = 0; r < CZ; ++r) {
-        Us[(k0 + r) * NX + i] = un[r];
-        Ws[(k0 + r) * NX + i] = wn[r];
-    }
+    constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
     __syncthreads();
     // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl)
     {
         const double rdt = 1.0 / dts;
+        const double *me = lds + k0 * RS;
+        double wlo = me[FW + i];
 #pragma unroll
         for (int r = 0; r < CZ; ++r) {
-            const int k = k0 + r;
-            double ue = Us[k * NX + ip1];
-            double wu = (r < CZ - 1) ? wn[r + 1] : (top ? 0.0 : Ws[(k + 1) * NX + i]);
-            Bf[k * NX + i] = ((ue - un[r]) * rdx + (wu - wn[r]) * rdz) * rdt;
+            const double *row = me + r * RS;
+            const double uc = row[FU + i], ue = row[FU + ip1];
+            const double whi = (r == CZ - 1 && top) ? 0.0 : row[RS + FW + i];
+            const double d = ((ue - uc) * rdx + (whi - wlo) * rdz) * rdt;
+            wlo = whi;
+            lds[(k0 + r) * RS + FB + i] = d;
         }
     }
     __syncthreads();
     // ---- forward FFT along x, two rows (2p, 2p+1) packed as one complex sequence ----------
     if (tid < 12 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W96^(n2*k1)
         const int p = tid / 12, n2 = tid - 12 * p;
-        double *R = Bf + (2 * p) * NX, *I = R + NX;
+        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
         double re[8], im[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) { re[n1] = R[12 * n1 + n2]; im[n1] = I[12 * n1 + n2]; }
@@ -270,7 +276,7 @@ __device__ __forceinline__ void project(double *__restrict__ Us, double *__restr
     __syncthreads();
     if (tid < 8 * (NZ / 2)) {           // pass B: DFT-12 over n2 for fixed k1 -> mode k1+8*k2 at 12*k1+k2
         const int p = tid / 8, k1 = tid - 8 * p;
-        double *R = Bf + (2 * p) * NX + 12 * k1, *I = R + NX;
+        double *R = lds + (2 * p) * RS + FB + 12 * k1, *I = R + RS;
         double re[12], im[12];
 #pragma unroll
         for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
@@ -283,10 +289,12 @@ __device__ __forceinline__ void project(double *__restrict__ Us, double *__restr
     if (tid < G::NH) {
         const int m = tid;
         const int q1 = mode_pos(m), q2 = mode_pos((NX - m) % NX);
+        const bool two = (q1 != q2);
         const double o = rdz * rdz, cpf = o * (double)NX;     // cp_k = o*inv_k, table holds inv_k/NX
         double yr = 0.0, yi = 0.0;
+#pragma unroll 4
         for (int p = 0; p < NZ / 2; ++p) {                   // forward elimination
-            double *R = Bf + (2 * p) * NX, *I = R + NX;
+            double *R = lds + (2 * p) * RS + FB, *I = R + RS;
             const double r1 = R[q1], r2 = R[q2], i1 = I[q1], i2 = I[q2];
             const double inv0 = tri_inv[(2 * p) * G::NH + m], inv1 = tri_inv[(2 * p + 1) * G::NH + m];
             const double a_re = 0.5 * (r1 + r2), a_im = 0.5 * (i1 - i2);   // row 2p   spectrum
@@ -294,31 +302,32 @@ __device__ __forceinline__ void project(double *__restrict__ Us, double *__restr
             yr = a_re * inv0 - (inv0 * cpf) * yr;
             yi = a_im * inv0 - (inv0 * cpf) * yi;
             R[q1] = yr;
-            if (q1 != q2) R[q2] = yi;
+            if (two) R[q2] = yi;
             yr = b_re * inv1 - (inv1 * cpf) * yr;
             yi = b_im * inv1 - (inv1 * cpf) * yi;
             I[q1] = yr;
-            if (q1 != q2) I[q2] = yi;
+            if (two) I[q2] = yi;
         }
         double xr = 0.0, xi = 0.0;
+#pragma unroll 4
         for (int p = NZ / 2 - 1; p >= 0; --p) {              // back substitution + repack
-            double *R = Bf + (2 * p) * NX, *I = R + NX;
+            double *R = lds + (2 * p) * RS + FB, *I = R + RS;
             const double cp1 = tri_inv[(2 * p + 1) * G::NH + m] * cpf, cp0 = tri_inv[(2 * p) * G::NH + m] * cpf;
-            double y1r = I[q1], y1i = (q1 == q2) ? 0.0 : I[q2];
-            double y0r = R[q1], y0i = (q1 == q2) ? 0.0 : R[q2];
+            const double y1r = I[q1], y1i = two ? I[q2] : 0.0;
+            const double y0r = R[q1], y0i = two ? R[q2] : 0.0;
             const double x1r = y1r - cp1 * xr, x1i = y1i - cp1 * xi;     // row 2p+1
             const double x0r = y0r - cp0 * x1r, x0i = y0i - cp0 * x1i;   // row 2p
             xr = x0r; xi = x0i;
             // Z[m] = A + iB, Z[N-m] = conj(A) + i conj(B)
             R[q1] = x0r - x1i; I[q1] = x0i + x1r;
-            if (q1 != q2) { R[q2] = x0r + x1i; I[q2] = x1r - x0i; }
+            if (two) { R[q2] = x0r + x1i; I[q2] = x1r - x0i; }
         }
     }
     __syncthreads();
     // ---- inverse FFT (swap re<->im roles) --------------------------------------------------
     if (tid < 8 * (NZ / 2)) {
         const int p = tid / 8, k1 = tid - 8 * p;
-        double *R = Bf + (2 * p) * NX + 12 * k1, *I = R + NX;
+        double *R = lds + (2 * p) * RS + FB + 12 * k1, *I = R + RS;
         double re[12], im[12];
 #pragma unroll
         for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
@@ -337,7 +346,7 @@ __device__ __forceinline__ void project(double *__restrict__ Us, double *__restr
     __syncthreads();
     if (tid < 12 * (NZ / 2)) {
         const int p = tid / 12, n2 = tid - 12 * p;
-        double *R = Bf + (2 * p) * NX, *I = R + NX;
+        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
         double re[8], im[8];
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) { re[k1] = R[12 * k1 + n2]; im[k1] = I[12 * k1 + n2]; }
@@ -348,16 +357,15 @@ __device__ __forceinline__ void project(double *__restrict__ Us, double *__restr
     __syncthreads();
     // ---- pressure_correct_velocities! ([OC] pressure_correction.jl) -------------------------
     {
-        double pdn = (k0 > 0) ? Bf[(k0 - 1) * NX + i] : 0.0;
+        double *me = lds + k0 * RS;
+        double pdn = (k0 > 0) ? me[-RS + FB + i] : 0.0;
 #pragma unroll
         for (int r = 0; r < CZ; ++r) {
-            const int k = k0 + r;
-            const double pc = Bf[k * NX + i], pw = Bf[k * NX + im1];
-            un[r] -= (pc - pw) * rdx * dts;
-            if (k > 0) wn[r] -= (pc - pdn) * rdz * dts;
+            double *row = me + r * RS;
+            const double pc = row[FB + i], pw = row[FB + im1];
+            row[FU + i] -= (pc - pw) * rdx * dts;
+            if (k0 + r > 0) row[FW + i] -= (pc - pdn) * rdz * dts;
             pdn = pc;
-            Us[k * NX + i] = un[r];
-            Ws[k * NX + i] = wn[r];
         }
     }
 }
@@ -369,10 +377,11 @@ template <int NX, int NZ>
 __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 {
     using G = Geo<NX, NZ>;
+    constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Us = lds, *Ws = lds + G::NCELL, *Bf = lds + 2 * G::NCELL, *Sc = lds + 3 * G::NCELL;
+    double *Sc = lds + 3 * G::NCELL;
     double *tw = Sc;                 // [12][8][2] twiddles c,s of W96^(n2*k1) = c - i s
-    double *scr = Sc + 192;          // reductions / column-scan partials (>= NT + 65 doubles)
+    double *scr = Sc + 192;          // reductions / column-scan partials (>= NT + 130 doubles)
 
     const int env = blockIdx.x;
     if (P.mask && !P.mask[env]) return;
@@ -423,36 +432,33 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         else Tb = T1;
     }
 
-    // ---- load (or generate) the state: own cells -> registers + LDS --------------------------
-    double un[CZ], wn[CZ], bn[CZ];
-    if (P.mode == MODE_RANDOM) {   // initialize_model, rbc_sim2D.jl:163-171
-        const uint64_t seed = P.seeds[env];
+    // ---- load (or generate) the state of the own cells --------------------------------------
+    double bn[CZ];
+    {
+        double *me = lds + k0 * RS + i;
+        if (P.mode == MODE_RANDOM) {   // initialize_model, rbc_sim2D.jl:163-171
+            const uint64_t seed = P.seeds[env];
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                const uint32_t id = (uint32_t)(k * NX + i);
+                me[r * RS + FU] = P.kick * normal_deviate(seed, 0, id);
+                me[r * RS + FW] = (k == 0) ? 0.0 : P.kick * normal_deviate(seed, 1, id);
+                const double z = (k + 0.5) * dz;
+                const double v = P.min_b + (P.lz - z) * P.delta_b / 2 + P.kick * normal_deviate(seed, 2, id);
+                me[r * RS + FB] = fmin(fmax(v, P.min_b), P.min_b + P.delta_b);
+            }
+        } else {
 #pragma unroll
-        for (int r = 0; r < CZ; ++r) {
-            const int k = k0 + r;
-            const uint32_t id = (uint32_t)(k * NX + i);
-            un[r] = P.kick * normal_deviate(seed, 0, id);
-            wn[r] = (k == 0) ? 0.0 : P.kick * normal_deviate(seed, 1, id);
-            const double z = (k + 0.5) * dz;
-            double v = P.min_b + (P.lz - z) * P.delta_b / 2 + P.kick * normal_deviate(seed, 2, id);
-            bn[r] = fmin(fmax(v, P.min_b), P.min_b + P.delta_b);
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                me[r * RS + FB] = gb_[k * NX + i];
+                me[r * RS + FU] = gu_[k * NX + i];
+                me[r * RS + FW] = (k == 0) ? 0.0 : gw_[k * NX + i];
+            }
         }
-    } else {
 #pragma unroll
-        for (int r = 0; r < CZ; ++r) {
-            const int k = k0 + r;
-            bn[r] = gb_[k * NX + i];
-            un[r] = gu_[k * NX + i];
-            wn[r] = (k == 0) ? 0.0 : gw_[k * NX + i];
-        }
+        for (int r = 0; r < CZ; ++r) bn[r] = me[r * RS + FB];
     }
-#pragma unroll
-    for (int r = 0; r < CZ; ++r) {
-        Us[(k0 + r) * NX + i] = un[r];
-        Ws[(k0 + r) * NX + i] = wn[r];
-        Bf[(k0 + r) * NX + i] = bn[r];
-    }
-    __syncthreads();
 
     double g0u[CZ], g0w[CZ], g0b[CZ];   // G^- (previous stage tendencies)
 #pragma unroll
@@ -463,9 +469,19 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
         // set!'s incompressibility projection with unit time step ([OC] set_nonhydrostatic_model.jl)
-        project<NX, NZ>(Us, Ws, Bf, tw, P.tri_inv, un, wn, 1.0, rdx, rdz, tid, i, ip1, im1, k0, top);
-        // Bf holds phi (pNHS); b stays in registers
+        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, i, ip1, im1, k0, top);
+        // the b slot now holds phi (pNHS); b stays in registers
+    } else {
+        __syncthreads();
     }
+
+    // column addresses (doubles) of the 7-point x stencil, shared by all fields and rows
+    const double *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
+    const double *cc0 = lds + k0 * RS + i;
+    const double *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
+    // row offset of (relative row rr, field f) with rr clamped into the domain (values read
+    // through a clamped index are never used: the wall-adjacent stencils select them away)
+    auto off = [&](int rr, int f) -> int { return min(max(rr, -k0), NZ - 1 - k0) * RS + f; };
 
     for (int st = 0; st < nstage; ++st) {
         const int sub = st / 3, ph = st - 3 * sub;
@@ -474,226 +490,210 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         const double gam = (ph == 0) ? 8.0 / 15.0 : (ph == 1 ? 5.0 / 12.0 : 3.0 / 4.0);
         const double zet = (ph == 0) ? 0.0 : (ph == 1 ? -17.0 / 60.0 : -5.0 / 12.0);
         const double dts = (gam + zet) * dt;
+        const bool dbg = (P.mode == MODE_TENDENCY);
+        double *dg = dbg ? P.dbg_g + (size_t)env * 3 * G::NCELL : nullptr;
 
-        // ---- hydrostatic pressure anomaly: x-difference of the column integral -------------
-        // pHY'[k] = pHY'[k+1] - b_face(k+1) dz  ([OC] update_hydrostatic_pressure.jl); G_u needs
-        // (pHY'[i]-pHY'[i-1])/dx = -dz/dx * sum_{k'>=k} (dbf[k'+1]),  dbf = face mean of (b[i]-b[i-1])
-        double dphy[CZ];
+        // ---- hydrostatic pressure anomaly ([OC] update_hydrostatic_pressure.jl) --------------
+        // pHY'[k] = pHY'[k+1] - b_face(k+1) dz.  G_u needs pHY'[i,k]-pHY'[i-1,k]
+        //         = -dz * sum_{k'>=k} mean(db[k'], db[k'+1]),  db[k] = b[i,k]-b[i-1,k].
+        // Pre-pass: the chunk totals; the u pass below walks DOWN its chunk and accumulates.
+        double db_top;   // db at the first row above the chunk (halo row for the top chunk)
         {
-            double db[CZ + 1];
-#pragma unroll
-            for (int r = 0; r <= CZ; ++r) {
-                const int k = k0 + r;
-                if (r == CZ && top) {
-                    // top halo cell from the Value BC (both columns)
-                    const double cN = Bf[(NZ - 1) * NX + i], cM = Bf[(NZ - 1) * NX + im1];
-                    const double hN = cN + ((P.min_b - cN) / hz) * dz, hM = cM + ((P.min_b - cM) / hz) * dz;
-                    db[r] = hN - hM;
-                } else {
-                    db[r] = Bf[k * NX + i] - Bf[k * NX + im1];
-                }
+            if (top) {
+                const double cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
+                const double hN = cN + ((P.min_b - cN) / hz) * dz, hM = cM + ((P.min_b - cM) / hz) * dz;
+                db_top = hN - hM;
+            } else {
+                db_top = cc0[CZ * RS + FB] - cm1[CZ * RS + FB];
             }
-            double acc = 0.0;
+            double acc = 0.0, dbu = db_top;
 #pragma unroll
-            for (int r = CZ - 1; r >= 0; --r) { acc += 0.5 * (db[r] + db[r + 1]); dphy[r] = acc; }
+            for (int r = CZ - 1; r >= 0; --r) {
+                const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
+                acc += 0.5 * (d + dbu);
+                dbu = d;
+            }
             scr[c * NX + i] = acc;
-            __syncthreads();
+        }
+        __syncthreads();
+        double un[CZ], wn[CZ];
+        // ======================= u tendency (walks down the chunk) ==============================
+        {
             double above = 0.0;
             for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) dphy[r] = -(dphy[r] + above) * dz;   // = pHY'[i,k]-pHY'[i-1,k]
-        }
-
-        double gn[CZ];
-        // ======================= b tendency =====================================================
-        {
-            // rolling column window of b around the face above the current cell
-            double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 relative to face k (face between w2,w3)
-            auto brow = [&](int k) -> double { return Bf[min(max(k, 0), NZ - 1) * NX + i]; };
-            w0 = brow(k0 - 3); w1 = brow(k0 - 2); w2 = brow(k0 - 1); w3 = brow(k0); w4 = brow(k0 + 1); w5 = brow(k0 + 2);
-            // flux through the bottom face of the chunk (face k0); wall -> 0
-            double fz_lo;
-            {
-                const double wv = Ws[k0 * NX + i];
-                fz_lo = bot ? 0.0 : upwz(wv, w0, w1, w2, w3, w4, w5, true, true);
+            double pacc = 0.0, dbu = db_top;
+            // z window of u around face k+1: rows k-2..k+3  (w0..w5), face between w2|w3
+            double w0, w1, w2, w3, w4, w5;
+            w0 = cc0[off(CZ - 3, FU)]; w1 = cc0[off(CZ - 2, FU)]; w2 = cc0[off(CZ - 1, FU)];
+            w3 = cc0[off(CZ, FU)]; w4 = cc0[off(CZ + 1, FU)]; w5 = cc0[off(CZ + 2, FU)];
+            // top face of the chunk (face k0+CZ): advecting w in x (Centered(4), periodic)
+            double wm_hi, wc_hi, fz_hi, uup;
+            if (top) {
+                wm_hi = 0.0; wc_hi = 0.0; fz_hi = 0.0;
+                uup = w2 + ((0.0 - w2) / hz) * dz;              // halo row above the top cell
+            } else {
+                wm_hi = cm1[CZ * RS + FW]; wc_hi = cc0[CZ * RS + FW];
+                const double wt = sym4(cm2[CZ * RS + FW], wm_hi, wc_hi, cp1[CZ * RS + FW]);
+                fz_hi = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
+                uup = w3;
             }
-            // halo value below the first cell (diffusion)
-            double bdn = bot ? (w3 + ((w3 - Tb) / hz) * (-dz)) : w2;
+#pragma unroll
+            for (int r = CZ - 1; r >= 0; --r) {
+                // slide the window down: now around face k (rows k-3..k+2)
+                w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = w0; w0 = cc0[off(r - 3, FU)];
+                const double u0 = w3;
+                const double um3 = cm3[r * RS + FU], um2 = cm2[r * RS + FU], um1 = cm1[r * RS + FU];
+                const double up1 = cp1[r * RS + FU], up2 = cp2[r * RS + FU], up3 = cp3[r * RS + FU];
+                // flux_uu at centres i-1 and i  (advective_momentum_flux_Uu)
+                const double ut_w = sym4(um2, um1, u0, up1);
+                const double ut_e = sym4(um1, u0, up1, up2);
+                const double fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
+                const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
+                // bottom face k of this cell
+                double fz_lo, udn, wm_lo, wc_lo;
+                if (r == 0 && bot) {
+                    fz_lo = 0.0; wm_lo = 0.0; wc_lo = 0.0;
+                    udn = u0 + ((u0 - 0.0) / hz) * (-dz);
+                } else {
+                    wm_lo = cm1[r * RS + FW]; wc_lo = cc0[r * RS + FW];
+                    const double wt = sym4(cm2[r * RS + FW], wm_lo, wc_lo, cp1[r * RS + FW]);
+                    // face k: 5th if 3<=k<=NZ-3, 3rd if 2<=k<=NZ-2, else 1st
+                    const bool ok5 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
+                    const bool ok3 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);
+                    fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
+                    udn = w2;
+                }
+                const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures, isotropic ScalarDiffusivity)
+                const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * (rdx * rdx)
+                                         + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
+                // hydrostatic pressure gradient
+                const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
+                pacc += 0.5 * (d + dbu);
+                dbu = d;
+                const double dphy = -(pacc + above) * dz;
+                const double g = vis - adv - dphy * rdx;
+                if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = g;
+                un[r] = u0 + dt * (gam * g + zet * g0u[r]);
+                g0u[r] = g;
+                fz_hi = fz_lo; uup = u0; wm_hi = wm_lo; wc_hi = wc_lo;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ======================= b tendency (walks up) ===========================================
+        {
+            double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
+            w0 = cc0[off(-3, FB)]; w1 = cc0[off(-2, FB)]; w2 = cc0[off(-1, FB)];
+            w3 = cc0[off(0, FB)]; w4 = cc0[off(1, FB)]; w5 = cc0[off(2, FB)];
+            double fz_lo = bot ? 0.0 : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
+            double bdn = bot ? (w3 + ((w3 - Tb) / hz) * (-dz)) : w2;      // Value BC halo below the first cell
 #pragma unroll
             for (int r = 0; r < CZ; ++r) {
-                const int k = k0 + r;
-                // slide window up by one: now centred on face k+1
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = brow(k + 3);
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = cc0[off(r + 3, FB)];   // now around face k+1
                 const double b0 = w2;
-                const double *row = Bf + k * NX;
-                const double bm3 = row[im3], bm2 = row[im2], bm1 = row[im1], bp1 = row[ip1], bp2 = row[ip2], bp3 = row[ip3];
-                const double ui = Us[k * NX + i], ue = Us[k * NX + ip1];
+                const double bm3 = cm3[r * RS + FB], bm2 = cm2[r * RS + FB], bm1 = cm1[r * RS + FB];
+                const double bp1 = cp1[r * RS + FB], bp2 = cp2[r * RS + FB], bp3 = cp3[r * RS + FB];
+                const double ui = cc0[r * RS + FU], ue = cp1[r * RS + FU];
                 const double fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
                 const double fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
-                // face k+1 (1-based face index k+2): 5th if 3<=k+1<=NZ-3, 3rd if 2<=k+1<=NZ-2
                 double fz_hi, bup;
                 if (r == CZ - 1 && top) {
                     fz_hi = 0.0;
                     bup = b0 + ((P.min_b - b0) / hz) * dz;
                 } else {
-                    const double wv = Ws[(k + 1) * NX + i];
                     const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
                     const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
-                    fz_hi = upwz(wv, w0, w1, w2, w3, w4, w5, ok5, ok3);
+                    fz_hi = upwz(cc0[(r + 1) * RS + FW], w0, w1, w2, w3, w4, w5, ok5, ok3);
                     bup = w3;
                 }
                 const double adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
                 const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * (rdx * rdx) + ((bup - b0) - (b0 - bdn)) * (rdz * rdz));
-                gn[r] = dif - adv;
-                fz_lo = fz_hi;
-                bdn = b0;
+                const double g = dif - adv;
+                if (dbg) dg[(k0 + r) * NX + i] = g;
+                bn[r] = b0 + dt * (gam * g + zet * g0b[r]);
+                g0b[r] = g;
+                fz_lo = fz_hi; bdn = b0;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (P.mode == MODE_TENDENCY) {
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) P.dbg_g[((size_t)env * 3 + 0) * G::NCELL + (k0 + r) * NX + i] = gn[r];
-        }
-#pragma unroll
-        for (int r = 0; r < CZ; ++r) {
-            bn[r] += dt * (gam * gn[r] + zet * g0b[r]);
-            g0b[r] = gn[r];
-        }
-        // ======================= u tendency =====================================================
+        // ======================= w tendency (faces k0..k0+7, walks up) ===========================
         {
-            auto urow = [&](int k) -> double { return Us[min(max(k, 0), NZ - 1) * NX + i]; };
-            double w0, w1, w2, w3, w4, w5;
-            w0 = urow(k0 - 3); w1 = urow(k0 - 2); w2 = urow(k0 - 1); w3 = urow(k0); w4 = urow(k0 + 1); w5 = urow(k0 + 2);
-            // z-face k0: advecting w interpolated in x to the u column (Centered(4), periodic)
-            double wm_lo = Ws[k0 * NX + im1], wc_lo = Ws[k0 * NX + i];   // w[i-1], w[i] at face k (viscous cross term)
-            double fz_lo;
-            {
-                const double wt = sym4(Ws[k0 * NX + im2], wm_lo, wc_lo, Ws[k0 * NX + ip1]);
-                fz_lo = bot ? 0.0 : upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
-            }
-            double udn = bot ? (w3 + ((w3 - 0.0) / hz) * (-dz)) : w2;
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) {
-                const int k = k0 + r;
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = urow(k + 3);
-                const double u0 = w2;
-                const double *row = Us + k * NX;
-                const double um3 = row[im3], um2 = row[im2], um1 = row[im1], up1 = row[ip1], up2 = row[ip2], up3 = row[ip3];
-                // flux_uu at centres i-1 and i  (advective_momentum_flux_Uu)
-                const double ut_w = sym4(um2, um1, u0, up1);          // centre i-1: faces i-2..i+1
-                const double ut_e = sym4(um1, u0, up1, up2);          // centre i
-                const double fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
-                const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
-                double fz_hi, uup, wm_hi, wc_hi;
-                if (r == CZ - 1 && top) {
-                    fz_hi = 0.0; wm_hi = 0.0; wc_hi = 0.0;
-                    uup = u0 + ((0.0 - u0) / hz) * dz;
-                } else {
-                    const double *wr = Ws + (k + 1) * NX;
-                    wm_hi = wr[im1]; wc_hi = wr[i];
-                    const double wt = sym4(wr[im2], wm_hi, wc_hi, wr[ip1]);
-                    const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
-                    const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
-                    fz_hi = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
-                    uup = w3;
-                }
-                const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
-                // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures isotropic ScalarDiffusivity)
-                const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * (rdx * rdx)
-                                         + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
-                gn[r] = vis - adv - dphy[r] * rdx;
-                fz_lo = fz_hi; udn = u0; wm_lo = wm_hi; wc_lo = wc_hi;
-            }
-        }
-        if (P.mode == MODE_TENDENCY) {
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) P.dbg_g[((size_t)env * 3 + 1) * G::NCELL + (k0 + r) * NX + i] = gn[r];
-        }
-#pragma unroll
-        for (int r = 0; r < CZ; ++r) {
-            un[r] += dt * (gam * gn[r] + zet * g0u[r]);
-            g0u[r] = gn[r];
-        }
-        // ======================= w tendency (faces k0..k0+7; wall face 0 never evolves) ========
-        {
-            auto wrow = [&](int k) -> double { return (k >= NZ) ? 0.0 : Ws[min(max(k, 0), NZ - 1) * NX + i]; };
-            auto urw = [&](int k, int col) -> double { return Us[min(max(k, 0), NZ - 1) * NX + col]; };
-            // w column window: faces k-2..k+3 around centre k (between faces k, k+1)
-            double w0, w1, w2, w3, w4, w5;
-            // start around centre k0-1: faces k0-3..k0+2
-            w0 = wrow(k0 - 3); w1 = wrow(k0 - 2); w2 = wrow(k0 - 1); w3 = wrow(k0); w4 = wrow(k0 + 1); w5 = wrow(k0 + 2);
-            // flux_ww at centre k0-1 (1-based centre index k0): 5th if 2<=kc<=NZ-3, 3rd if 1<=kc<=NZ-2
-            double fz_lo = 0.0;
-            if (!bot) {
-                const double wt = symz(w1, w2, w3, w4, true);
-                fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
-            }
+            auto wld = [&](int rr) -> double { return (k0 + rr >= NZ) ? 0.0 : cc0[off(rr, FW)]; };
+            double w0, w1, w2, w3, w4, w5;   // w faces k-2..k+3 around centre k (between w2|w3)
+            w0 = wld(-3); w1 = wld(-2); w2 = wld(-1); w3 = wld(0); w4 = wld(1); w5 = wld(2);   // centre k0-1
+            double fz_lo = 0.0;              // flux_ww at centre k0-1
+            if (!bot) fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);
             // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
-            double a0 = urw(k0 - 2, i), a1 = urw(k0 - 1, i), a2 = urw(k0, i), a3 = urw(k0 + 1, i);
-            double e0 = urw(k0 - 2, ip1), e1 = urw(k0 - 1, ip1), e2 = urw(k0, ip1), e3 = urw(k0 + 1, ip1);
+            double a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
+            double e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
 #pragma unroll
             for (int r = 0; r < CZ; ++r) {
-                const int k = k0 + r;          // z-face k, and centre k above it
                 if (r > 0) {
-                    a0 = a1; a1 = a2; a2 = a3; a3 = urw(k + 1, i);
-                    e0 = e1; e1 = e2; e2 = e3; e3 = urw(k + 1, ip1);
+                    a0 = a1; a1 = a2; a2 = a3; a3 = cc0[off(r + 1, FU)];
+                    e0 = e1; e1 = e2; e2 = e3; e3 = cp1[off(r + 1, FU)];
                 }
-                // slide w window to centre k: faces k-2..k+3
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = wrow(k + 3);
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = wld(r + 3);   // centre k: faces k-2..k+3
                 const double wc = w2;          // w at face k
-                // flux_ww at centre k (0-based): 5th if 2<=k<=NZ-3, 3rd if 1<=k<=NZ-2, else 1st
+                // flux_ww at centre k: 5th if 2<=k<=NZ-3, 3rd if 1<=k<=NZ-2, else 1st
                 const bool c5 = ((r >= 2) || !bot) && ((r <= CZ - 3) || !top);
                 const bool c3 = ((r >= 1) || !bot) && ((r <= CZ - 2) || !top);
 #if RBC_SYMLEVEL
-                const bool c4 = c3;            // Centered(4) own buffer: 1<=k<=NZ-2
+                const bool c4 = c3;
 #else
                 const bool c4 = c5;
 #endif
-                const double wt = symz(w1, w2, w3, w4, c4);
-                const double fz_hi = upwz(wt, w0, w1, w2, w3, w4, w5, c5, c3);
-                if (bot && r == 0) { gn[r] = 0.0; fz_lo = fz_hi; continue; }
-                // flux_uw at (x-face i, z-face k) and (x-face i+1, z-face k)
+                const double fz_hi = upwz(symz(w1, w2, w3, w4, c4), w0, w1, w2, w3, w4, w5, c5, c3);
+                double g = 0.0;
+                if (!(bot && r == 0)) {
 #if RBC_SYMLEVEL
-                const bool f4 = ((r >= 2) || !bot);                    // 2<=k<=NZ-2 (k<=NZ-1 always here... top face NZ excluded)
-                const bool f4t = f4 && ((r <= CZ - 2) || !top);
+                    const bool f4 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);       // 2<=k<=NZ-2
 #else
-                const bool f4t = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
+                    const bool f4 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);       // 3<=k<=NZ-3
 #endif
-                const double ut_w = symz(a0, a1, a2, a3, f4t);
-                const double ut_e = symz(e0, e1, e2, e3, f4t);
-                const double *row = Ws + k * NX;
-                const double wm3 = row[im3], wm2 = row[im2], wm1 = row[im1], wp1 = row[ip1], wp2 = row[ip2], wp3 = row[ip3];
-                const double fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
-                const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
-                const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
-                const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
-                                         + 2.0 * ((w3 - wc) - (wc - w1)) * (rdz * rdz));
-                gn[r] = vis - adv;
+                    const double ut_w = symz(a0, a1, a2, a3, f4);
+                    const double ut_e = symz(e0, e1, e2, e3, f4);
+                    const double wm3 = cm3[r * RS + FW], wm2 = cm2[r * RS + FW], wm1 = cm1[r * RS + FW];
+                    const double wp1 = cp1[r * RS + FW], wp2 = cp2[r * RS + FW], wp3 = cp3[r * RS + FW];
+                    const double fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
+                    const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
+                    const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                    const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
+                                             + 2.0 * ((w3 - wc) - (wc - w1)) * (rdz * rdz));
+                    g = vis - adv;
+                }
+                if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = g;
+                wn[r] = wc + dt * (gam * g + zet * g0w[r]);
+                g0w[r] = g;
                 fz_lo = fz_hi;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (P.mode == MODE_TENDENCY) {
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) P.dbg_g[((size_t)env * 3 + 2) * G::NCELL + (k0 + r) * NX + i] = gn[r];
-            return;
-        }
-#pragma unroll
-        for (int r = 0; r < CZ; ++r) {
-            wn[r] += dt * (gam * gn[r] + zet * g0w[r]);
-            g0w[r] = gn[r];
-        }
+        if (dbg) return;
         __syncthreads();   // every read of the old state is done
-        project<NX, NZ>(Us, Ws, Bf, tw, P.tri_inv, un, wn, dts, rdx, rdz, tid, i, ip1, im1, k0, top);
-        if (st + 1 < nstage) {
-            __syncthreads();   // phi reads done -> Bf takes the new b
+        {
+            double *me = lds + k0 * RS + i;
 #pragma unroll
-            for (int r = 0; r < CZ; ++r) Bf[(k0 + r) * NX + i] = bn[r];
+            for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = un[r]; me[r * RS + FW] = wn[r]; }
+        }
+        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, i, ip1, im1, k0, top);
+        if (st + 1 < nstage) {
+            __syncthreads();   // phi reads done -> the b slot takes the new b
+            double *me = lds + k0 * RS + i;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) me[r * RS + FB] = bn[r];
             __syncthreads();
         }
     }
 
     // =========================== outputs ========================================================
-    // here: un, wn, bn = final own-cell values; LDS U, W = final u, w; Bf = phi of the last stage
+    // here: LDS u,w = final velocities (own cells), b slot = phi of the last stage, bn = final b
     __syncthreads();
+    double un[CZ], wn[CZ];
+    {
+        const double *me = lds + k0 * RS + i;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) { un[r] = me[r * RS + FU]; wn[r] = me[r * RS + FW]; }
+    }
     // state back to HBM
 #pragma unroll
     for (int r = 0; r < CZ; ++r) {
@@ -715,20 +715,20 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     double ph[CZ];
     double psum = 0.0;
 #pragma unroll
-    for (int r = 0; r < CZ; ++r) { ph[r] = Bf[(k0 + r) * NX + i]; psum += ph[r]; }
+    for (int r = 0; r < CZ; ++r) { ph[r] = lds[(k0 + r) * RS + FB + i]; psum += ph[r]; }
     psum = block_sum<G::NT>(psum, scr, tid);
     const double pmean = psum / (double)G::NCELL;
 #pragma unroll
     for (int r = 0; r < CZ; ++r) ph[r] -= pmean;
 
-    // pHY' (absolute) by the same column scan; Bf (free now) takes the final b
+    // pHY' (absolute) by the same column scan; the b slot (free now) takes the final b
     double phy[CZ];
     {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < CZ; ++r) Bf[(k0 + r) * NX + i] = bn[r];
+        for (int r = 0; r < CZ; ++r) lds[(k0 + r) * RS + FB + i] = bn[r];
         __syncthreads();
-        const double babove = top ? (bn[CZ - 1] + ((P.min_b - bn[CZ - 1]) / hz) * dz) : Bf[(k0 + CZ) * NX + i];
+        const double babove = top ? (bn[CZ - 1] + ((P.min_b - bn[CZ - 1]) / hz) * dz) : lds[(k0 + CZ) * RS + FB + i];
         double acc = 0.0;
 #pragma unroll
         for (int r = CZ - 1; r >= 0; --r) {
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #pragma unroll
         for (int r = 0; r < CZ; ++r) phy[r] = -(phy[r] + above) * dz;
     }
-    // now LDS: U=u, W=w, Bf=b (final)
+    // now LDS: u, w, b slots = final fields
 
     // A11 observation / state (float32, channel order b,u,w,pHY',pNHS; layout [c][z][x])
     {
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             const int row = tid / 12, seg = tid - 12 * row;   // NT = 12*NZ threads: NX/8 = 12 segments per row
             double s = 0.0;
             if ((row % stz) == 0)
-                for (int j = 0; j < 8; ++j) { const int x = 8 * seg + j; if ((x % stx) == 0) s += Bf[row * NX + x]; }
+                for (int j = 0; j < 8; ++j) { const int x = 8 * seg + j; if ((x % stx) == 0) s += lds[row * RS + FB + x]; }
             scr[tid] = s;
         }
         __syncthreads();
