@@ -132,6 +132,9 @@ double rbc_algorithmic_bytes_per_env_step(rbc_handle *h);
 int  rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw);
 /* run `nsub` RK3 substeps of size dt with the given actions (no counters touched)          */
 int  rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt);
+/* diagnostic builds only (-DRBC_STAMPS=1): per-phase shader-clock cycles of the last launch,
+   out[B][32]; returns RBC_ERR_INVALID in the shipped build                                 */
+int  rbc_debug_stamps(rbc_handle *h, unsigned long long *out);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ namespace rbc {
 
 constexpr int CZ = 8;              // cells per thread along z
 constexpr int MAX_HEATERS = 32;
-constexpr int SCRATCH_DOUBLES = 1280;
+constexpr int SCRATCH_DOUBLES = 1090;  // twiddles (192) + reduction scratch (NT+130); sits in FRONT of the fields
 
 enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENCY = 3 };
 
@@ -35,10 +35,28 @@ enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENC
 #define RBC_SYMLEVEL 0
 #endif
 
+// Diagnostic build only (-DRBC_STAMPS=1, never shipped): thread 0 of every workgroup accumulates
+// shader-clock cycles per phase into stamps[env][32]; outputs are unaffected.
+#ifndef RBC_STAMPS
+#define RBC_STAMPS 0
+#endif
+#if RBC_STAMPS
+#define STAMP(id)                                                                                   \
+    do {                                                                                            \
+        if (tid == 0 || tid == (int)blockDim.x - 1) {                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                             \
+            stamp_acc[id] += t_ - stamp_last;                                                       \
+            stamp_last = t_;                                                                        \
+        }                                                                                           \
+    } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 struct Params2D {
     double *fields;            // [B][ b(NZ*NX) | u(NZ*NX) | w((NZ+1)*NX) ] float64
     const float *actions;      // [B][heaters]
-    const double *ra;          // [B]
+    const double *nu_kappa;    // [B][2]: nu = sqrt(Pr/Ra), kappa = 1/sqrt(Pr*Ra) (rbc_sim2D_api.jl:40-41), host-computed
     const uint8_t *mask;       // [B] or nullptr
     const uint64_t *seeds;     // [B] (MODE_RANDOM)
     const double *tri_inv;     // [NZ][NX/2+1] : 1/(pivot*NX) of the z tridiagonal systems
@@ -47,7 +65,9 @@ struct Params2D {
     double *nusselt;           // [B][2]
     int *flags;                // [B]
     double *dbg_g;             // [B][3][NZ][NX] (MODE_TENDENCY)
-    double lx, lz, pr, min_b, delta_b, heater_limit, kick;
+    unsigned long long *stamps; // [B][32] (RBC_STAMPS builds)
+    double lx, lz, min_b, delta_b, heater_limit, kick;
+    double dx, dz, rdx, rdz, rdx2, rdz2, rhz;   // uniform grid metrics (host-computed so they stay scalar-loadable)
     double dt, dt_last;
     int nsub;                  // number of RK3 substeps (the last one uses dt_last)
     int heaters;
@@ -93,9 +113,21 @@ __device__ __forceinline__ double right3(double c, double d, double e)
 __device__ __forceinline__ double sym4(double b, double c, double d, double e)
 { return (-b + 7.0 * c + 7.0 * d - e) * (1.0 / 12.0); }
 
-// upwinded value: vel>0 takes the left-biased reconstruction (== upwind_biased_product/vel)
+// upwinded value: vel>0 takes the left-biased reconstruction (== upwind_biased_product/vel).
+// Both reconstructions are materialised (empty asm) so hipcc emits one v_cndmask pair instead of
+// a divergent if/else around each stencil: the sign of the velocity varies from lane to lane.
+#ifndef RBC_BRANCHFREE
+#define RBC_BRANCHFREE 1
+#endif
+__device__ __forceinline__ double pick(double vel, double L, double R)
+{
+#if RBC_BRANCHFREE
+    asm volatile("" : "+v"(L), "+v"(R));
+#endif
+    return vel * (vel > 0.0 ? L : R);
+}
 __device__ __forceinline__ double upw5(double vel, double a, double b, double c, double d, double e, double f)
-{ return vel * (vel > 0.0 ? left5(a, b, c, d, e) : right5(b, c, d, e, f)); }
+{ return pick(vel, left5(a, b, c, d, e), right5(b, c, d, e, f)); }
 
 // wall-aware version: ok5/ok3 select 5th / 3rd / 1st order (both biases share one test)
 __device__ __forceinline__ double upwz(double vel, double a, double b, double c, double d, double e, double f,
@@ -103,7 +135,7 @@ __device__ __forceinline__ double upwz(double vel, double a, double b, double c,
 {
     double L = ok5 ? left5(a, b, c, d, e) : (ok3 ? left3(b, c, d) : c);
     double R = ok5 ? right5(b, c, d, e, f) : (ok3 ? right3(c, d, e) : d);
-    return vel * (vel > 0.0 ? L : R);
+    return pick(vel, L, R);
 }
 __device__ __forceinline__ double symz(double b, double c, double d, double e, bool ok4)
 { return ok4 ? sym4(b, c, d, e) : 0.5 * (c + d); }
@@ -196,7 +228,12 @@ struct Geo {
     static constexpr int NH = NX / 2 + 1;                 // stored Fourier columns
     static constexpr int RS = 3 * NX;                     // LDS row stride (doubles)
     static constexpr int FU = 0, FW = NX, FB = 2 * NX;    // field offsets inside a row
-    static constexpr size_t LDS_BYTES = (size_t)(3 * NCELL + SCRATCH_DOUBLES) * sizeof(double);
+    static constexpr int GUARD = 3;                       // stencil rows that may be touched beyond a wall
+    // [scratch | NZ field rows | GUARD rows]: the scratch doubles as the guard below row 0, so every
+    // stencil row offset is a compile-time immediate (values read from guards are selected away)
+    static_assert(SCRATCH_DOUBLES >= GUARD * RS, "front scratch must cover the lower guard rows");
+    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH_DOUBLES + 3 * NCELL + GUARD * RS) * sizeof(double);
+    static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
     static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
 };
 
@@ -234,11 +271,14 @@ __device__ inline double block_sum(double v, double *scr, int tid)
 template <int NX, int NZ>
 __device__ __forceinline__ void project(double *__restrict__ lds, const double *__restrict__ tw,
                                         const double *__restrict__ tri_inv, double dts, double rdx, double rdz,
-                                        int tid, int i, int ip1, int im1, int k0, bool top)
+                                        int tid, int i, int ip1, int im1, int k0, bool top,
+                                        unsigned long long *stamp_acc, unsigned long long &stamp_last)
 {
     using G = Geo<NX, NZ>;
     constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
+    (void)stamp_acc; (void)stamp_last;
     __syncthreads();
+    STAMP(5);
     // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl)
     {
         const double rdt = 1.0 / dts;
@@ -255,6 +295,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         }
     }
     __syncthreads();
+    STAMP(6);
     // ---- forward FFT along x, two rows (2p, 2p+1) packed as one complex sequence ----------
     if (tid < 12 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W96^(n2*k1)
         const int p = tid / 12, n2 = tid - 12 * p;
@@ -274,6 +315,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         for (int k1 = 0; k1 < 8; ++k1) { R[12 * k1 + n2] = re[k1]; I[12 * k1 + n2] = im[k1]; }
     }
     __syncthreads();
+    STAMP(7);
     if (tid < 8 * (NZ / 2)) {           // pass B: DFT-12 over n2 for fixed k1 -> mode k1+8*k2 at 12*k1+k2
         const int p = tid / 8, k1 = tid - 8 * p;
         double *R = lds + (2 * p) * RS + FB + 12 * k1, *I = R + RS;
@@ -285,6 +327,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
     }
     __syncthreads();
+    STAMP(8);
     // ---- z solve per wavenumber (Thomas); unpack / repack of the row pairing fused in ------
     if (tid < G::NH) {
         const int m = tid;
@@ -324,6 +367,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         }
     }
     __syncthreads();
+    STAMP(9);
     // ---- inverse FFT (swap re<->im roles) --------------------------------------------------
     if (tid < 8 * (NZ / 2)) {
         const int p = tid / 8, k1 = tid - 8 * p;
@@ -344,6 +388,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
     }
     __syncthreads();
+    STAMP(10);
     if (tid < 12 * (NZ / 2)) {
         const int p = tid / 12, n2 = tid - 12 * p;
         double *R = lds + (2 * p) * RS + FB, *I = R + RS;
@@ -355,6 +400,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         for (int n1 = 0; n1 < 8; ++n1) { R[12 * n1 + n2] = re[n1]; I[12 * n1 + n2] = im[n1]; }
     }
     __syncthreads();
+    STAMP(11);
     // ---- pressure_correct_velocities! ([OC] pressure_correction.jl) -------------------------
     {
         double *me = lds + k0 * RS;
@@ -378,23 +424,28 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 {
     using G = Geo<NX, NZ>;
     constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Sc = lds + 3 * G::NCELL;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    double *Sc = lds_raw;
+    double *lds = lds_raw + SCRATCH_DOUBLES;   // field rows start here
     double *tw = Sc;                 // [12][8][2] twiddles c,s of W96^(n2*k1) = c - i s
-    double *scr = Sc + 192;          // reductions / column-scan partials (>= NT + 130 doubles)
+    double *scr = Sc + 192;          // reductions / column-scan partials (NT + 130 doubles)
 
     const int env = blockIdx.x;
     if (P.mask && !P.mask[env]) return;
     const int tid = threadIdx.x;
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = 0;
+#if RBC_STAMPS
+    if (tid == 0 || tid == (int)blockDim.x - 1) stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     const int c = tid / NX, i = tid - c * NX;
     const int k0 = c * CZ;
     const bool bot = (c == 0), top = (c == G::NC - 1);
     const int ip1 = (i + 1 == NX) ? 0 : i + 1, ip2 = (ip1 + 1 == NX) ? 0 : ip1 + 1, ip3 = (ip2 + 1 == NX) ? 0 : ip2 + 1;
     const int im1 = (i == 0) ? NX - 1 : i - 1, im2 = (im1 == 0) ? NX - 1 : im1 - 1, im3 = (im2 == 0) ? NX - 1 : im2 - 1;
 
-    const double dx = P.lx / NX, dz = P.lz / NZ, rdx = 1.0 / dx, rdz = 1.0 / dz;
-    const double ra = P.ra[env];
-    const double nu = sqrt(P.pr / ra), kap = 1.0 / sqrt(P.pr * ra);   // rbc_sim2D_api.jl:40-41
+    const double dx = P.dx, dz = P.dz, rdx = P.rdx, rdz = P.rdz;
+    const double nu = P.nu_kappa[2 * env], kap = P.nu_kappa[2 * env + 1];
 
     if (tid < 96) {
         const int n2 = tid / 8, k1 = tid - 8 * n2;
@@ -464,12 +515,12 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #pragma unroll
     for (int r = 0; r < CZ; ++r) { g0u[r] = 0.0; g0w[r] = 0.0; g0b[r] = 0.0; }
 
-    const double hz = dz / 2;
+    const double rhz = P.rhz;   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
     const int nstage = (P.mode == MODE_STEP) ? 3 * P.nsub : ((P.mode == MODE_TENDENCY) ? 1 : 0);
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
         // set!'s incompressibility projection with unit time step ([OC] set_nonhydrostatic_model.jl)
-        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, i, ip1, im1, k0, top);
+        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, i, ip1, im1, k0, top, stamp_acc, stamp_last);
         // the b slot now holds phi (pNHS); b stays in registers
     } else {
         __syncthreads();
@@ -479,10 +530,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     const double *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
     const double *cc0 = lds + k0 * RS + i;
     const double *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
-    // row offset of (relative row rr, field f) with rr clamped into the domain (values read
-    // through a clamped index are never used: the wall-adjacent stencils select them away)
-    auto off = [&](int rr, int f) -> int { return min(max(rr, -k0), NZ - 1 - k0) * RS + f; };
+    // row offset of (relative row rr, field f).  Rows outside the domain fall into the guard
+    // rows / front scratch: whatever is read there is selected away by the wall-adjacent stencils
+    auto off = [&](int rr, int f) -> int { return rr * RS + f; };
 
+    STAMP(0);
     for (int st = 0; st < nstage; ++st) {
         const int sub = st / 3, ph = st - 3 * sub;
         const double dt = (sub == P.nsub - 1) ? P.dt_last : P.dt;
@@ -492,6 +544,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         const double dts = (gam + zet) * dt;
         const bool dbg = (P.mode == MODE_TENDENCY);
         double *dg = dbg ? P.dbg_g + (size_t)env * 3 * G::NCELL : nullptr;
+        STAMP(14);
 
         // ---- hydrostatic pressure anomaly ([OC] update_hydrostatic_pressure.jl) --------------
         // pHY'[k] = pHY'[k+1] - b_face(k+1) dz.  G_u needs pHY'[i,k]-pHY'[i-1,k]
@@ -499,12 +552,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         // Pre-pass: the chunk totals; the u pass below walks DOWN its chunk and accumulates.
         double db_top;   // db at the first row above the chunk (halo row for the top chunk)
         {
-            if (top) {
+            {   // branch-free: the top chunk takes the Value-BC halo row, the others the row above
                 const double cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
-                const double hN = cN + ((P.min_b - cN) / hz) * dz, hM = cM + ((P.min_b - cM) / hz) * dz;
-                db_top = hN - hM;
-            } else {
-                db_top = cc0[CZ * RS + FB] - cm1[CZ * RS + FB];
+                const double hN = cN + ((P.min_b - cN) * rhz) * dz, hM = cM + ((P.min_b - cM) * rhz) * dz;
+                const double dn = cc0[off(CZ, FB)] - cm1[off(CZ, FB)];
+                db_top = top ? (hN - hM) : dn;
             }
             double acc = 0.0, dbu = db_top;
 #pragma unroll
@@ -515,7 +567,9 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             }
             scr[c * NX + i] = acc;
         }
+        STAMP(15);
         __syncthreads();
+        STAMP(1);
         double un[CZ], wn[CZ];
         // ======================= u tendency (walks down the chunk) ==============================
         {
@@ -528,14 +582,12 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             w3 = cc0[off(CZ, FU)]; w4 = cc0[off(CZ + 1, FU)]; w5 = cc0[off(CZ + 2, FU)];
             // top face of the chunk (face k0+CZ): advecting w in x (Centered(4), periodic)
             double wm_hi, wc_hi, fz_hi, uup;
-            if (top) {
-                wm_hi = 0.0; wc_hi = 0.0; fz_hi = 0.0;
-                uup = w2 + ((0.0 - w2) / hz) * dz;              // halo row above the top cell
-            } else {
-                wm_hi = cm1[CZ * RS + FW]; wc_hi = cc0[CZ * RS + FW];
-                const double wt = sym4(cm2[CZ * RS + FW], wm_hi, wc_hi, cp1[CZ * RS + FW]);
-                fz_hi = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
-                uup = w3;
+            {   // branch-free (clamped loads, selects): the top wall face carries no flux and w=0
+                wm_hi = top ? 0.0 : cm1[off(CZ, FW)]; wc_hi = top ? 0.0 : cc0[off(CZ, FW)];
+                const double wt = sym4(cm2[off(CZ, FW)], wm_hi, wc_hi, cp1[off(CZ, FW)]);
+                const double f = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
+                fz_hi = top ? 0.0 : f;
+                uup = top ? (w2 + ((0.0 - w2) * rhz) * dz) : w3;   // halo row above the top cell
             }
 #pragma unroll
             for (int r = CZ - 1; r >= 0; --r) {
@@ -551,21 +603,20 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
                 // bottom face k of this cell
                 double fz_lo, udn, wm_lo, wc_lo;
-                if (r == 0 && bot) {
-                    fz_lo = 0.0; wm_lo = 0.0; wc_lo = 0.0;
-                    udn = u0 + ((u0 - 0.0) / hz) * (-dz);
-                } else {
+                {   // the bottom wall row of w is identically 0 in LDS, so its flux vanishes by itself
                     wm_lo = cm1[r * RS + FW]; wc_lo = cc0[r * RS + FW];
                     const double wt = sym4(cm2[r * RS + FW], wm_lo, wc_lo, cp1[r * RS + FW]);
                     // face k: 5th if 3<=k<=NZ-3, 3rd if 2<=k<=NZ-2, else 1st
                     const bool ok5 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
                     const bool ok3 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);
                     fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
-                    udn = w2;
+                    const bool wall = (r == 0) && bot;
+                    fz_lo = wall ? 0.0 : fz_lo;
+                    udn = wall ? (u0 + ((u0 - 0.0) * rhz) * (-dz)) : w2;
                 }
                 const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
                 // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures, isotropic ScalarDiffusivity)
-                const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * (rdx * rdx)
+                const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * P.rdx2
                                          + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
                 // hydrostatic pressure gradient
                 const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
@@ -580,13 +631,14 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(2);
         // ======================= b tendency (walks up) ===========================================
         {
             double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
             w0 = cc0[off(-3, FB)]; w1 = cc0[off(-2, FB)]; w2 = cc0[off(-1, FB)];
             w3 = cc0[off(0, FB)]; w4 = cc0[off(1, FB)]; w5 = cc0[off(2, FB)];
             double fz_lo = bot ? 0.0 : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
-            double bdn = bot ? (w3 + ((w3 - Tb) / hz) * (-dz)) : w2;      // Value BC halo below the first cell
+            double bdn = bot ? (w3 + ((w3 - Tb) * rhz) * (-dz)) : w2;      // Value BC halo below the first cell
 #pragma unroll
             for (int r = 0; r < CZ; ++r) {
                 w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = cc0[off(r + 3, FB)];   // now around face k+1
@@ -597,17 +649,16 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 const double fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
                 const double fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
                 double fz_hi, bup;
-                if (r == CZ - 1 && top) {
-                    fz_hi = 0.0;
-                    bup = b0 + ((P.min_b - b0) / hz) * dz;
-                } else {
+                {
                     const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
                     const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
-                    fz_hi = upwz(cc0[(r + 1) * RS + FW], w0, w1, w2, w3, w4, w5, ok5, ok3);
-                    bup = w3;
+                    const bool wall = (r == CZ - 1) && top;
+                    fz_hi = upwz(cc0[off(r + 1, FW)], w0, w1, w2, w3, w4, w5, ok5, ok3);
+                    fz_hi = wall ? 0.0 : fz_hi;
+                    bup = wall ? (b0 + ((P.min_b - b0) * rhz) * dz) : w3;
                 }
                 const double adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
-                const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * (rdx * rdx) + ((bup - b0) - (b0 - bdn)) * (rdz * rdz));
+                const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * P.rdx2 + ((bup - b0) - (b0 - bdn)) * P.rdz2);
                 const double g = dif - adv;
                 if (dbg) dg[(k0 + r) * NX + i] = g;
                 bn[r] = b0 + dt * (gam * g + zet * g0b[r]);
@@ -616,13 +667,22 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(3);
+        if (!dbg) {
+            // every thread has finished reading the old b: its slot now parks the new u so that the
+            // heaviest pass below runs with one new-value array fewer in registers
+            __syncthreads();
+            double *me = lds + k0 * RS + i;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) me[r * RS + FB] = un[r];
+        }
         // ======================= w tendency (faces k0..k0+7, walks up) ===========================
         {
             auto wld = [&](int rr) -> double { return (k0 + rr >= NZ) ? 0.0 : cc0[off(rr, FW)]; };
             double w0, w1, w2, w3, w4, w5;   // w faces k-2..k+3 around centre k (between w2|w3)
             w0 = wld(-3); w1 = wld(-2); w2 = wld(-1); w3 = wld(0); w4 = wld(1); w5 = wld(2);   // centre k0-1
-            double fz_lo = 0.0;              // flux_ww at centre k0-1
-            if (!bot) fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);
+            double fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);   // flux_ww at centre k0-1
+            fz_lo = bot ? 0.0 : fz_lo;
             // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
             double a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
             double e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
@@ -643,8 +703,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 const bool c4 = c5;
 #endif
                 const double fz_hi = upwz(symz(w1, w2, w3, w4, c4), w0, w1, w2, w3, w4, w5, c5, c3);
-                double g = 0.0;
-                if (!(bot && r == 0)) {
+                double g;
+                {
 #if RBC_SYMLEVEL
                     const bool f4 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);       // 2<=k<=NZ-2
 #else
@@ -658,8 +718,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                     const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
                     const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
                     const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
-                                             + 2.0 * ((w3 - wc) - (wc - w1)) * (rdz * rdz));
-                    g = vis - adv;
+                                             + 2.0 * ((w3 - wc) - (wc - w1)) * P.rdz2);
+                    g = ((r == 0) && bot) ? 0.0 : (vis - adv);
                 }
                 if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = g;
                 wn[r] = wc + dt * (gam * g + zet * g0w[r]);
@@ -669,13 +729,15 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             }
         }
         if (dbg) return;
+        STAMP(4);
         __syncthreads();   // every read of the old state is done
         {
             double *me = lds + k0 * RS + i;
 #pragma unroll
-            for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = un[r]; me[r * RS + FW] = wn[r]; }
+            for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = me[r * RS + FB]; me[r * RS + FW] = wn[r]; }
         }
-        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, i, ip1, im1, k0, top);
+        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, i, ip1, im1, k0, top, stamp_acc, stamp_last);
+        STAMP(12);
         if (st + 1 < nstage) {
             __syncthreads();   // phi reads done -> the b slot takes the new b
             double *me = lds + k0 * RS + i;
@@ -683,6 +745,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             for (int r = 0; r < CZ; ++r) me[r * RS + FB] = bn[r];
             __syncthreads();
         }
+        STAMP(13);
     }
 
     // =========================== outputs ========================================================
@@ -728,7 +791,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #pragma unroll
         for (int r = 0; r < CZ; ++r) lds[(k0 + r) * RS + FB + i] = bn[r];
         __syncthreads();
-        const double babove = top ? (bn[CZ - 1] + ((P.min_b - bn[CZ - 1]) / hz) * dz) : lds[(k0 + CZ) * RS + FB + i];
+        const double babove = top ? (bn[CZ - 1] + ((P.min_b - bn[CZ - 1]) * rhz) * dz) : lds[(k0 + CZ) * RS + FB + i];
         double acc = 0.0;
 #pragma unroll
         for (int r = CZ - 1; r >= 0; --r) {
@@ -812,6 +875,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         }
         __syncthreads();
     }
+    STAMP(0);
+#if RBC_STAMPS
+    if ((tid == 0 || tid == (int)blockDim.x - 1) && P.stamps)
+        for (int j = 0; j < 16; ++j) P.stamps[(size_t)env * 32 + (tid ? 16 : 0) + j] = stamp_acc[j];
+#endif
 }
 
 }  // namespace rbc

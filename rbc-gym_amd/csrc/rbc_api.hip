@@ -44,6 +44,7 @@ struct rbc_handle {
     uint8_t *d_mask = nullptr;
     uint64_t *d_seeds = nullptr;
     int *d_flags = nullptr;
+    unsigned long long *d_stamps = nullptr;   // RBC_STAMPS diagnostic builds only
     std::vector<double> t;
     std::vector<int64_t> step;
     std::vector<uint8_t> inited;
@@ -94,7 +95,7 @@ rbc::Params2D base_params(const rbc_handle *h)
     rbc::Params2D p{};
     p.fields = h->d_fields;
     p.actions = nullptr;
-    p.ra = h->d_ra;
+    p.nu_kappa = h->d_ra;
     p.mask = nullptr;
     p.seeds = h->d_seeds;
     p.tri_inv = h->d_tri;
@@ -103,7 +104,11 @@ rbc::Params2D base_params(const rbc_handle *h)
     p.nusselt = h->d_nu;
     p.flags = h->d_flags;
     p.dbg_g = h->d_dbg;
-    p.lx = h->cfg.lx; p.lz = h->cfg.lz; p.pr = h->cfg.pr;
+    p.stamps = h->d_stamps;
+    p.lx = h->cfg.lx; p.lz = h->cfg.lz;
+    p.dx = h->cfg.lx / h->nx; p.dz = h->cfg.lz / h->nz;
+    p.rdx = 1.0 / p.dx; p.rdz = 1.0 / p.dz; p.rdx2 = p.rdx * p.rdx; p.rdz2 = p.rdz * p.rdz;
+    p.rhz = 1.0 / (p.dz / 2);
     p.min_b = h->cfg.min_b; p.delta_b = h->cfg.delta_b;
     p.heater_limit = h->cfg.heater_limit; p.kick = h->cfg.random_kick;
     p.dt = h->cfg.dt_solver; p.dt_last = h->dt_last; p.nsub = h->nsub;
@@ -227,7 +232,7 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     const size_t B = h->B;
     CREATE_TRY(hipMalloc(&h->d_fields, B * h->env_stride * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_fields, 0, B * h->env_stride * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_ra, B * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_ra, B * 2 * sizeof(double)));   // (nu, kappa) per env
     CREATE_TRY(hipMalloc(&h->d_actions, B * cfg->heaters * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->d_mask, B));
     CREATE_TRY(hipMalloc(&h->d_seeds, B * sizeof(uint64_t)));
@@ -236,12 +241,17 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     CREATE_TRY(hipMalloc(&h->d_nu, B * 2 * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_flags, B * sizeof(int)));
     CREATE_TRY(hipMemset(h->d_flags, 0, B * sizeof(int)));
+#if RBC_STAMPS
+    CREATE_TRY(hipMalloc(&h->d_stamps, B * 32 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(h->d_stamps, 0, B * 32 * sizeof(unsigned long long)));
+#endif
     {
         std::vector<double> tab = tri_table(h->nx, h->nz, cfg->lx, cfg->lz);
         CREATE_TRY(hipMalloc(&h->d_tri, tab.size() * sizeof(double)));
         CREATE_TRY(hipMemcpy(h->d_tri, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-        std::vector<double> ra(B, cfg->ra);
-        CREATE_TRY(hipMemcpy(h->d_ra, ra.data(), B * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> nk(2 * B);
+        for (size_t e = 0; e < B; ++e) { nk[2 * e] = std::sqrt(cfg->pr / cfg->ra); nk[2 * e + 1] = 1.0 / std::sqrt(cfg->pr * cfg->ra); }
+        CREATE_TRY(hipMemcpy(h->d_ra, nk.data(), nk.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes));
@@ -259,7 +269,7 @@ int rbc_destroy(rbc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_actions, h->d_obs, h->d_state,
-                    h->d_mask, h->d_seeds, h->d_flags};
+                    h->d_mask, h->d_seeds, h->d_flags, h->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -293,7 +303,12 @@ int rbc_set_rayleigh(rbc_handle *h, const double *ra)
         if (!(ra[e] > 0)) return fail(RBC_ERR_INVALID, "Rayleigh numbers must be positive");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(h->d_ra, ra, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> nk(2 * (size_t)h->B);
+    for (int e = 0; e < h->B; ++e) {   // rbc_sim2D_api.jl:40-41
+        nk[2 * e] = std::sqrt(h->cfg.pr / ra[e]);
+        nk[2 * e + 1] = 1.0 / std::sqrt(h->cfg.pr * ra[e]);
+    }
+    HIP_TRY(hipMemcpy(h->d_ra, nk.data(), nk.size() * sizeof(double), hipMemcpyHostToDevice));
     return RBC_OK;
 }
 
@@ -535,6 +550,17 @@ int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double
     HIP_TRY(hipMemcpy2D(gb, nc * sizeof(double), h->d_dbg, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy2D(gu, nc * sizeof(double), h->d_dbg + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy2D(gw, nc * sizeof(double), h->d_dbg + 2 * nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    return RBC_OK;
+}
+
+/* diagnostic builds (-DRBC_STAMPS=1): per-phase shader-clock cycles of the last launch, [B][32] */
+int rbc_debug_stamps(rbc_handle *h, unsigned long long *out)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!h->d_stamps || !out) return fail(RBC_ERR_INVALID, "not a stamp build");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->d_stamps, (size_t)h->B * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RBC_OK;
 }
 
