@@ -44,7 +44,7 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(nsteps=3):
+def cpu_baseline(nsteps=6):
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py
@@ -91,7 +91,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rbc_gym import _native
+    from rbc_gym import _native, sharding
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -105,16 +105,16 @@ def main():
     sim = _native.NativeSim(batch=B, device=local_rank, ra=args.ra)
     stream = torch.cuda.current_stream(dev)
     sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)
-    seeds = np.arange(B, dtype=np.uint64) + np.uint64(1234 + rank * B)
-    sim.reset(seeds)
+    start, count = sharding.shard(world * B, world, rank)      # weak scaling: B envs on every GPU
+    assert count == B
+    sim.reset(sharding.env_seeds(1234, start, count))
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     actions = (torch.rand((K + W, B, 12), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).contiguous()
     stride = B * 12 * 4
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        sharding.barrier(dist if world > 1 else None)
 
     for n in range(W):
         sim.step_dev(actions.data_ptr() + n * stride)
@@ -135,14 +135,18 @@ def main():
     nan_envs = int(flags.sum())
     nus, _ = sim.get_nusselt()
 
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    nans = torch.tensor([nan_envs], device=dev, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(nans, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
+    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=dev, dist=dist if world > 1 else None)
 
     if rank == 0:
+        traffic, traffic_src = None, None
+        try:                       # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))[-1]
+            summ = json.load(open(latest))
+            if summ.get("bench_line_under_profiler", {}).get("config", {}).get("global_batch") == world * B or world == 1:
+                traffic, traffic_src = summ.get("hbm_traffic_bytes_per_launch"), os.path.relpath(latest, ROOT)
+        except Exception:
+            pass
         alg_bytes = sim.algorithmic_bytes_per_env_step() * B          # per launch
         avg_ms = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms == avg_ms else None
@@ -164,13 +168,15 @@ def main():
                        "global_batch": world * B, "substeps_per_env_step": 50,
                        "parallelism": f"env-sharded x{world} (no collective on the step path)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE)*1024, separate rocprofv3 --pmc passes",
+                         "traffic_source": traffic_src,
                          "kernel": "rbc2d_kernel<96,64>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = 10*F*C*s per RK3 substep (F=3,C=6144,s=8) x 50 x batch; the kernel "
                                  "keeps the state in LDS for the whole control interval, so real HBM traffic is ~0.4 MB/env"},
             "cpu_baseline": cpu,
-            "nan_envs": int(nans.item()),
+            "nan_envs": nan_total,
             "mean_nusselt_state": float(np.mean(nus)),
         }
         print(json.dumps(out))

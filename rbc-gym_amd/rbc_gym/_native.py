@@ -65,6 +65,7 @@ SYMBOLS = {
     "rbc_algorithmic_bytes_per_env_step": (C.c_double, [_vp]),
     "rbc_debug_tendencies": (C.c_int, [_vp, _fp, _dp, _dp, _dp]),
     "rbc_debug_substeps": (C.c_int, [_vp, _fp, C.c_int, C.c_double]),
+    "rbc_debug_stamps": (C.c_int, [_vp, _u64p]),
 }
 
 _lib = None

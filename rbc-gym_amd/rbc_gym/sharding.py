@@ -1,0 +1,37 @@
+"""Multi-GPU: env instances are independent, so N GPUs = N contiguous shards of the global env
+batch, one process per GPU, and NO collective on the step path.  torch.distributed
+(RCCL on the GPU box, gloo in the CPU tests) is only used to line the ranks up around the timed
+region and to reduce the timing / NaN counters."""
+import numpy as np
+
+
+def shard(global_batch, world, rank):
+    """contiguous env range [start, start+count) of `rank`; the first global_batch % world ranks get one extra env."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(global_batch), int(world))
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def env_seeds(base_seed, start, count):
+    """per-env seeds of the synthetic workload: base_seed + global env index."""
+    return np.uint64(base_seed) + np.arange(start, start + count, dtype=np.uint64)
+
+
+def barrier(dist=None):
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def reduce_run(elapsed, nan_envs, device=None, dist=None):
+    """-> (max elapsed over ranks, total NaN envs) ; identity when not distributed."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed), int(nan_envs)
+    import torch
+    t = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    n = torch.tensor([int(nan_envs)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(n.item())

@@ -1,0 +1,155 @@
+"""Batched on-device VectorEnv: replaces the reference's process-per-env fan-out.
+
+The reference vectorises with `gym.make_vec(id, num_envs, vectorization_mode="async")`
+(example/run_vectorized.py:11-20) or SB3's SubprocVecEnv (experiments/run_sarl.py:152-153):
+one OS process and one Julia runtime per env.  Here all `num_envs` instances live in the HBM of
+one MI355X and one kernel launch advances them all.  API and semantics follow gymnasium 1.1.x
+`VectorEnv`: `reset(seed=s)` seeds env i with s+i, NEXT_STEP autoreset, infos as dict of stacked
+arrays with `_key` masks.
+"""
+import logging
+from pathlib import Path
+
+import numpy as np
+
+from ._gym import gym
+from . import _native
+from .checkpoint import read_checkpoint
+from .envs.rbc2D import build_spaces, pick_checkpoint_episode, sim_kwargs
+
+
+class DeviceArray:
+    """Zero-copy view of a device buffer of the simulation (`__cuda_array_interface__`, which
+    PyTorch-ROCm understands: `torch.as_tensor(DeviceArray(...), device="cuda")`)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+def _batch_space(space, n):
+    return gym.spaces.Box(np.broadcast_to(space.low, (n,) + space.shape).copy(),
+                          np.broadcast_to(space.high, (n,) + space.shape).copy(),
+                          shape=(n,) + space.shape, dtype=space.dtype)
+
+
+class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
+    metadata = {"render_modes": [], "autoreset_mode": "NextStep"}
+
+    def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
+                 state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
+                 use_gpu=True, checkpoint=None, render_mode=None, device=0, info_state=True, **_ignored):
+        self.num_envs = int(num_envs)
+        self.ra = rayleigh_number
+        self.episode_length = episode_length
+        self.observation_shape = list(observation_shape)
+        self.state_shape = list(state_shape)
+        self.temperature_difference = [1, 2]
+        self.heater_segments = heater_segments
+        self.heater_limit = heater_limit
+        self.heater_duration = heater_duration
+        self.include_pressure = pressure
+        self.episode_steps = int(episode_length / heater_duration)
+        self.checkpoint = checkpoint
+        self.render_mode = render_mode
+        self.info_state = info_state
+        self.logger = logging.getLogger(__name__)
+
+        self.single_action_space, self.single_observation_space = build_spaces(self.observation_shape, heater_segments,
+                                                                               heater_limit, pressure)
+        self.action_space = _batch_space(self.single_action_space, self.num_envs)
+        self.observation_space = _batch_space(self.single_observation_space, self.num_envs)
+
+        ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
+        self.sim = _native.NativeSim(batch=self.num_envs, device=device,
+                                     **sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments,
+                                                  heater_limit, heater_duration))
+        if np.ndim(rayleigh_number) > 0:                 # per-env Rayleigh numbers (Ra sweeps)
+            self.sim.set_rayleigh(np.asarray(rayleigh_number, dtype=np.float64))
+        self._nch = 5 if pressure else 3
+        self._seeds = None
+        self._autoreset = np.zeros(self.num_envs, dtype=bool)
+        self._ckpt = None
+        self.closed = False
+
+    # ------------------------------------------------------------------------------------------
+    def _reset_envs(self, mask):
+        seeds = self._seeds
+        if self.checkpoint:
+            path = Path(self.checkpoint)
+            if not path.exists():
+                raise FileNotFoundError(f"Checkpoint file {path} does not exist. Please provide a valid checkpoint directory.")
+            if self._ckpt is None:
+                self._ckpt = read_checkpoint(path)
+            ck = self._ckpt
+            idx = np.array([pick_checkpoint_episode(ck["num_episodes"], s) for s in seeds])
+            self.sim.reset_from_arrays(ck["b"][idx], ck["u"][idx], ck["w"][idx], mask=mask)
+        else:
+            self.sim.reset(np.asarray(seeds, dtype=np.uint64), mask=mask)
+
+    def _infos(self):
+        t, step = self.sim.get_info()
+        nus, nuo = self.sim.get_nusselt()
+        ones = np.ones(self.num_envs, dtype=bool)
+        info = {"t": t, "_t": ones, "step": step, "_step": ones.copy(),
+                "nusselt_state": nus, "_nusselt_state": ones.copy(), "nusselt_obs": nuo, "_nusselt_obs": ones.copy()}
+        if self.info_state:
+            info["state"] = self.sim.get_state(self._nch)
+            info["_state"] = ones.copy()
+        return info, t, nuo
+
+    def reset(self, *, seed=None, options=None):
+        super().reset(seed=seed)
+        n = self.num_envs
+        if seed is None:
+            if self._seeds is None:                      # each sub-env keeps the seed it drew first (rbc2D.py:150)
+                self._seeds = np.random.SeedSequence().generate_state(n, dtype=np.uint64) % np.uint64(2**31)
+        elif np.ndim(seed) == 0:
+            self._seeds = (np.uint64(int(seed)) + np.arange(n, dtype=np.uint64))
+        else:
+            s = list(seed)
+            if len(s) != n:
+                raise ValueError("seed sequence must have num_envs entries")
+            old = self._seeds if self._seeds is not None else np.random.SeedSequence().generate_state(n, dtype=np.uint64) % np.uint64(2**31)
+            self._seeds = np.array([old[i] if s[i] is None else s[i] for i in range(n)], dtype=np.uint64)
+        self._reset_envs(None)
+        self._autoreset[:] = False
+        info, _, _ = self._infos()
+        return self.sim.get_obs(self._nch), info
+
+    def step(self, actions):
+        a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.heater_segments)
+        if not self.sim.step(a):
+            bad = np.nonzero(self.sim.get_flags())[0]
+            if not np.all(self._autoreset[bad]):         # an env that is re-initialised below may be ignored
+                raise RuntimeError("Error in simulation step, probably NaN values")
+        resetting = self._autoreset.copy()
+        if resetting.any():                              # NEXT_STEP autoreset: these envs restart now, their action is ignored
+            self._reset_envs(resetting.astype(np.uint8))
+        info, t, nuo = self._infos()
+        obs = self.sim.get_obs(self._nch)
+        rewards = -nuo
+        rewards[resetting] = 0.0
+        terminated = np.zeros(self.num_envs, dtype=bool)
+        truncated = (t >= self.episode_length) & ~resetting
+        self._autoreset = truncated.copy()
+        return obs, rewards, terminated, truncated, info
+
+    # -- device-resident rollout API (zero-copy PyTorch-ROCm tensors) --------------------------------
+    def device_views(self):
+        p = self.sim.dev_ptrs()
+        B, (oz, ox), (nz, nx) = self.num_envs, self.observation_shape, self.state_shape
+        return {"obs": DeviceArray(p["obs"], (B, 5, oz, ox), "<f4", self), "state": DeviceArray(p["state"], (B, 5, nz, nx), "<f4", self),
+                "nusselt": DeviceArray(p["nusselt"], (B, 2), "<f8", self), "flags": DeviceArray(p["flags"], (B,), "<i4", self)}
+
+    def step_device(self, actions_device_ptr):
+        """Advance all envs with actions already on the device ([B][heaters] float32); no host copy,
+        no autoreset, asynchronous on the simulation's stream."""
+        self.sim.step_dev(actions_device_ptr)
+
+    def close(self, **kwargs):
+        if getattr(self, "sim", None) is not None:
+            self.sim.close()
+            self.sim = None
+        self.closed = True

@@ -108,3 +108,18 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def small_h5():
+    """ckpt2d_small.h5: 2 episodes of train/ckpt_ra10000 re-written with h5py in the reference
+    writer's layout (attrs num_episodes/start_seed, contiguous f64 datasets (Nz[+1],1,Nx,E)) --
+    input for the dependency-free HDF5 reader test."""
+    with h5py.File(f"{REF}/train/ckpt_ra10000.h5", "r") as f, h5py.File(f"{OUT}/ckpt2d_small.h5", "w", libver="earliest") as g:
+        g.attrs["num_episodes"] = np.int64(2)
+        g.attrs["start_seed"] = np.int64(f.attrs["start_seed"])
+        for k in ("b", "u", "w"):
+            g.create_dataset(k, data=f[k][..., :2])
+
+
+if __name__ == "__main__":
+    small_h5()

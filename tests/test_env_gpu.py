@@ -1,0 +1,171 @@
+"""GPU: the drop-in layer end to end -- gym.make / gym.make_vec on the native stepper, return
+conventions of rbc2D.py, NEXT_STEP autoreset, seeding, checkpoints, device views, and the
+size-independent properties at BASELINE.json's full batch."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ID = "rbc_gym/RayleighBenardConvection2D-v0"
+
+
+@pytest.fixture(scope="module")
+def gym():
+    import rbc_gym  # noqa: F401  (registers the ids)
+    from rbc_gym._gym import gym
+    return gym
+
+
+def test_single_env_contract(gym):
+    env = gym.make(ID, heater_duration=0.3, episode_length=0.9)
+    assert env.unwrapped.episode_steps == 3 and env.unwrapped.ra == 10_000 and env.unwrapped.state_shape == [64, 96]
+    obs, info = env.reset(seed=5)
+    assert obs.shape == (3, 8, 48) and obs.dtype == np.float32
+    assert set(info) == {"t", "step", "nusselt_state", "nusselt_obs", "state"}            # rbc2D.py:206-212
+    assert info["t"] == 0.0 and info["step"] == 1 and info["state"].shape == (3, 64, 96) and info["state"].dtype == np.float32
+    assert isinstance(info["nusselt_state"], float)
+    assert np.array_equal(obs, info["state"][:, 0:64:8, 0:96:2])
+    a = env.action_space.sample()
+    obs, r, term, trunc, info = env.step(a)
+    assert isinstance(r, float) and r == -info["nusselt_obs"] and term is False and trunc is False
+    assert abs(info["t"] - 0.3) < 1e-12 and info["step"] == 2
+    env.step(a)
+    *_, trunc, info = env.step(a)
+    assert trunc is True and info["t"] >= 0.9                                        # rbc2D.py:179-180
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env.step(None)                                                                  # rbc2D.py:164-166
+        assert any("zero action" in str(x.message) for x in w)
+    env.close()
+
+
+def test_seeding_reproduces_and_default_seed_is_sticky(gym):
+    env = gym.make(ID, heater_duration=0.3)
+    o1, _ = env.reset(seed=42)
+    o2, _ = env.reset(seed=42)
+    o3, _ = env.reset()                      # quirk: reset(seed=None) keeps np_random_seed -> the same initial state
+    o4, _ = env.reset(seed=43)
+    assert np.array_equal(o1, o2) and np.array_equal(o1, o3) and not np.array_equal(o1, o4)
+    env.close()
+
+
+def test_pressure_and_custom_sensor_grid(gym):
+    env = gym.make(ID, pressure=True, observation_shape=[64, 96], heater_duration=0.3)     # example/run_2D.py:5
+    obs, info = env.reset(seed=1)
+    assert obs.shape == (5, 64, 96) and env.observation_space.shape == (5, 64, 96)
+    assert np.array_equal(obs, info["state"])
+    assert abs(info["nusselt_state"] - info["nusselt_obs"]) < 1e-12                  # sensors == state grid
+    env.close()
+
+
+def test_checkpoint_kwarg(gym, golden_dir, ckpt_ra1e4):
+    env = gym.make(ID, checkpoint=os.path.join(golden_dir, "ckpt2d_small.h5"), heater_duration=0.3)
+    obs, info = env.reset(seed=3)
+    cand = [ckpt_ra1e4["b"][e].astype(np.float32) for e in range(2)]
+    assert any(np.array_equal(info["state"][0], c) for c in cand)
+    assert 3.99 < info["nusselt_state"] < 4.01                                        # pin P2
+    env.close()
+    bad = gym.make(ID, checkpoint="/nonexistent/ckpt.h5")
+    with pytest.raises(FileNotFoundError):
+        bad.reset()
+    bad.close()
+
+
+def test_render_rgb_array(gym):
+    env = gym.make(ID, render_mode="rgb_array", heater_duration=0.3)
+    env.reset(seed=0)
+    img = env.render()
+    assert img.shape == (64, 96, 3) and img.dtype == np.uint8
+    env.close()
+
+
+def test_vector_env_matches_single_envs_and_autoresets(gym):
+    n = 4
+    venv = gym.make_vec(ID, num_envs=n, vectorization_mode="async", heater_duration=0.3, episode_length=0.6)
+    assert venv.num_envs == n and venv.single_action_space.shape == (12,) and venv.action_space.shape == (n, 12)
+    assert venv.observation_space.shape == (n, 3, 8, 48)
+    obs, info = venv.reset(seed=100)
+    assert obs.shape == (n, 3, 8, 48) and info["t"].shape == (n,) and info["_t"].all() and info["state"].shape == (n, 3, 64, 96)
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (3, n, 12)).astype(np.float32)
+    singles = []
+    for i in range(n):                                   # gymnasium: reset(seed=s) seeds sub-env i with s+i
+        e = gym.make(ID, heater_duration=0.3, episode_length=0.6)
+        o, _ = e.reset(seed=100 + i)
+        assert np.array_equal(o, obs[i])
+        singles.append(e)
+    o1, r1, te, tr, inf = venv.step(acts[0])
+    assert r1.shape == (n,) and r1.dtype == np.float64 and te.dtype == bool and not tr.any()
+    for i, e in enumerate(singles):
+        o, r, *_ = e.step(acts[0][i])
+        assert np.array_equal(o, o1[i]) and r == r1[i]
+    o2, r2, te, tr, inf = venv.step(acts[1])
+    assert tr.all() and np.allclose(inf["t"], 0.6)       # episode_length reached -> truncated
+    o3, r3, te, tr, inf = venv.step(acts[2])             # NEXT_STEP autoreset: this call resets, action ignored
+    assert not tr.any() and np.all(r3 == 0) and np.all(inf["t"] == 0) and np.all(inf["step"] == 1)
+    assert np.array_equal(o3, obs)                       # same seeds -> same initial observations
+    venv.close()
+    for e in singles:
+        e.close()
+
+
+def test_device_views_are_zero_copy_torch_tensors(gym):
+    torch = pytest.importorskip("torch")
+    venv = gym.make_vec(ID, num_envs=8, heater_duration=0.3)
+    obs, _ = venv.reset(seed=1)
+    v = venv.device_views()
+    t_obs = torch.as_tensor(v["obs"], device="cuda")
+    assert t_obs.shape == (8, 5, 8, 48) and t_obs.is_cuda
+    assert np.array_equal(t_obs[:, :3].cpu().numpy(), obs)
+    acts = torch.rand((8, 12), device="cuda") * 2 - 1
+    torch.cuda.synchronize()
+    venv.step_device(acts.data_ptr())
+    venv.sim.synchronize()
+    nu = torch.as_tensor(v["nusselt"], device="cuda").cpu().numpy()
+    hs, ho = venv.sim.get_nusselt()
+    assert np.array_equal(nu[:, 0], hs) and np.array_equal(nu[:, 1], ho)
+    assert not np.array_equal(torch.as_tensor(v["obs"], device="cuda")[:, :3].cpu().numpy(), obs)
+    venv.close()
+
+
+def test_full_batch_properties():
+    """BASELINE.json configs[1] size (B=1024): properties that need no oracle run --
+    exact discrete incompressibility, bitwise run-to-run determinism, independence from the batch
+    composition, and x-translation equivariance by one heater segment (8 cells)."""
+    from rbc_gym import _native
+    B = 1024
+    rng = np.random.default_rng(7)
+    act = rng.uniform(-1, 1, (B, 12)).astype(np.float32)
+    seeds = np.arange(B, dtype=np.uint64) + 1234
+
+    def run(actions, b0=None):
+        sim = _native.NativeSim(batch=B, dt_control=0.3)
+        if b0 is None:
+            sim.reset(seeds)
+        else:
+            sim.reset_from_arrays(*b0)
+        start = sim.get_fields()
+        assert sim.step(actions)
+        out = sim.get_fields() + sim.get_nusselt() + (sim.get_obs(5),)
+        sim.close()
+        return start, out
+
+    start, out = run(act)
+    b, u, w = out[:3]
+    dx, dz = 2 * np.pi / 96, 2 / 64
+    div = (np.roll(u, -1, 2) - u) / dx + (w[:, 1:] - w[:, :-1]) / dz
+    assert np.abs(div).max() < 2e-13
+    assert np.all(w[:, 0] == 0) and np.all(w[:, -1] == 0) and np.isfinite(b).all()
+    assert b.min() > 0.2 and b.max() < 2.8                                   # |T_bottom - 2| <= 0.75
+    _, again = run(act)
+    for x, y in zip(out, again):
+        assert np.array_equal(x, y)                                           # deterministic, bitwise
+    # translation: env e shifted by 8 cells with its action rolled by one segment
+    sh = tuple(np.roll(f, 8, axis=2) for f in start)
+    _, shifted = run(np.roll(act, 1, axis=1), b0=sh)
+    for x, y in zip(out[:3], shifted[:3]):
+        assert np.abs(np.roll(x, 8, axis=2) - y).max() < 1e-11
+    assert np.abs(out[3] - shifted[3]).max() < 1e-10                          # Nusselt on the full state is shift invariant
