@@ -20,7 +20,7 @@ def gym():
 
 
 def test_single_env_contract(gym):
-    env = gym.make(ID, heater_duration=0.3, episode_length=0.9)
+    env = gym.make(ID, heater_duration=0.25, episode_length=0.75)     # binary-exact times: t accumulates by += like api:87
     assert env.unwrapped.episode_steps == 3 and env.unwrapped.ra == 10_000 and env.unwrapped.state_shape == [64, 96]
     obs, info = env.reset(seed=5)
     assert obs.shape == (3, 8, 48) and obs.dtype == np.float32
@@ -31,10 +31,10 @@ def test_single_env_contract(gym):
     a = env.action_space.sample()
     obs, r, term, trunc, info = env.step(a)
     assert isinstance(r, float) and r == -info["nusselt_obs"] and term is False and trunc is False
-    assert abs(info["t"] - 0.3) < 1e-12 and info["step"] == 2
+    assert info["t"] == 0.25 and info["step"] == 2
     env.step(a)
     *_, trunc, info = env.step(a)
-    assert trunc is True and info["t"] >= 0.9                                        # rbc2D.py:179-180
+    assert trunc is True and info["t"] >= 0.75                                       # rbc2D.py:179-180
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         env.step(None)                                                                  # rbc2D.py:164-166
@@ -84,7 +84,7 @@ def test_render_rgb_array(gym):
 
 def test_vector_env_matches_single_envs_and_autoresets(gym):
     n = 4
-    venv = gym.make_vec(ID, num_envs=n, vectorization_mode="async", heater_duration=0.3, episode_length=0.6)
+    venv = gym.make_vec(ID, num_envs=n, vectorization_mode="async", heater_duration=0.25, episode_length=0.5)
     assert venv.num_envs == n and venv.single_action_space.shape == (12,) and venv.action_space.shape == (n, 12)
     assert venv.observation_space.shape == (n, 3, 8, 48)
     obs, info = venv.reset(seed=100)
@@ -93,7 +93,7 @@ def test_vector_env_matches_single_envs_and_autoresets(gym):
     acts = rng.uniform(-1, 1, (3, n, 12)).astype(np.float32)
     singles = []
     for i in range(n):                                   # gymnasium: reset(seed=s) seeds sub-env i with s+i
-        e = gym.make(ID, heater_duration=0.3, episode_length=0.6)
+        e = gym.make(ID, heater_duration=0.25, episode_length=0.5)
         o, _ = e.reset(seed=100 + i)
         assert np.array_equal(o, obs[i])
         singles.append(e)
@@ -103,7 +103,7 @@ def test_vector_env_matches_single_envs_and_autoresets(gym):
         o, r, *_ = e.step(acts[0][i])
         assert np.array_equal(o, o1[i]) and r == r1[i]
     o2, r2, te, tr, inf = venv.step(acts[1])
-    assert tr.all() and np.allclose(inf["t"], 0.6)       # episode_length reached -> truncated
+    assert tr.all() and np.all(inf["t"] == 0.5)       # episode_length reached -> truncated
     o3, r3, te, tr, inf = venv.step(acts[2])             # NEXT_STEP autoreset: this call resets, action ignored
     assert not tr.any() and np.all(r3 == 0) and np.all(inf["t"] == 0) and np.all(inf["step"] == 1)
     assert np.array_equal(o3, obs)                       # same seeds -> same initial observations
