@@ -133,7 +133,7 @@ int  rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, doubl
 /* run `nsub` RK3 substeps of size dt with the given actions (no counters touched)          */
 int  rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt);
 /* diagnostic builds only (-DRBC_STAMPS=1): per-phase shader-clock cycles of the last launch,
-   out[B][32]; returns RBC_ERR_INVALID in the shipped build                                 */
+   out[B][64]; returns RBC_ERR_INVALID in the shipped build                                 */
 int  rbc_debug_stamps(rbc_handle *h, unsigned long long *out);
 
 #ifdef __cplusplus

@@ -50,7 +50,7 @@ enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENC
         }                                                                                           \
     } while (0)
 #else
-#define STAMP(id) do { } while (0)
+#define STAMP(id) asm volatile("; PHASE_MARK " #id)
 #endif
 
 struct Params2D {
@@ -59,13 +59,13 @@ struct Params2D {
     const double *nu_kappa;    // [B][2]: nu = sqrt(Pr/Ra), kappa = 1/sqrt(Pr*Ra) (rbc_sim2D_api.jl:40-41), host-computed
     const uint8_t *mask;       // [B] or nullptr
     const uint64_t *seeds;     // [B] (MODE_RANDOM)
-    const double *tri_inv;     // [NZ][NX/2+1] : 1/(pivot*NX) of the z tridiagonal systems
+    const double *tri_inv;     // [NZ/2+1][NX/2+1]: half-sweep pivots 1/(piv*NX*f) + junction row (see tri_table)
     float *obs;                // [B][5][obs_nz][obs_nx]
     float *state32;            // [B][5][NZ][NX]
     double *nusselt;           // [B][2]
     int *flags;                // [B]
     double *dbg_g;             // [B][3][NZ][NX] (MODE_TENDENCY)
-    unsigned long long *stamps; // [B][32] (RBC_STAMPS builds)
+    unsigned long long *stamps; // [B][64] (RBC_STAMPS builds)
     double lx, lz, min_b, delta_b, heater_limit, kick;
     double dx, dz, rdx, rdz, rdx2, rdz2, rhz;   // uniform grid metrics (host-computed so they stay scalar-loadable)
     double dt, dt_last;
@@ -328,43 +328,90 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     }
     __syncthreads();
     STAMP(8);
-    // ---- z solve per wavenumber (Thomas); unpack / repack of the row pairing fused in ------
-    if (tid < G::NH) {
-        const int m = tid;
-        const int q1 = mode_pos(m), q2 = mode_pos((NX - m) % NX);
-        const bool two = (q1 != q2);
-        const double o = rdz * rdz, cpf = o * (double)NX;     // cp_k = o*inv_k, table holds inv_k/NX
-        double yr = 0.0, yi = 0.0;
-#pragma unroll 4
-        for (int p = 0; p < NZ / 2; ++p) {                   // forward elimination
-            double *R = lds + (2 * p) * RS + FB, *I = R + RS;
-            const double r1 = R[q1], r2 = R[q2], i1 = I[q1], i2 = I[q2];
-            const double inv0 = tri_inv[(2 * p) * G::NH + m], inv1 = tri_inv[(2 * p + 1) * G::NH + m];
-            const double a_re = 0.5 * (r1 + r2), a_im = 0.5 * (i1 - i2);   // row 2p   spectrum
-            const double b_re = 0.5 * (i1 + i2), b_im = 0.5 * (r2 - r1);   // row 2p+1 spectrum
-            yr = a_re * inv0 - (inv0 * cpf) * yr;
-            yi = a_im * inv0 - (inv0 * cpf) * yi;
-            R[q1] = yr;
-            if (two) R[q2] = yi;
-            yr = b_re * inv1 - (inv1 * cpf) * yr;
-            yi = b_im * inv1 - (inv1 * cpf) * yi;
-            I[q1] = yr;
-            if (two) I[q2] = yi;
+    // ---- z solve per wavenumber -------------------------------------------------------------
+    // (1) unpack the row pairing in place: row 2p <- 2*spectrum of row 2p, row 2p+1 <- 2*spectrum of
+    //     row 2p+1, each in half-complex form (Re of mode m at mode_pos(m), Im at mode_pos(NX-m));
+    //     the factor 2 is folded into the pivot table.  Modes 0 and NX/2 are already separated.
+    for (int idx = tid; idx < (NX / 2 - 1) * (NZ / 2); idx += G::NT) {
+        const int p = idx / (NX / 2 - 1), m = 1 + idx - (NX / 2 - 1) * p;
+        const int q1 = mode_pos(m), q2 = mode_pos(NX - m);
+        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
+        const double r1 = R[q1], r2 = R[q2], i1 = I[q1], i2 = I[q2];
+        R[q1] = r1 + r2; R[q2] = i1 - i2;
+        I[q1] = i1 + i2; I[q2] = r2 - r1;
+    }
+    __syncthreads();
+    STAMP(16);
+    // (2) the 96 real tridiagonal systems (one per half-complex column), each eliminated from BOTH
+    //     walls at once: lanes 0..95 sweep rows 0..NZ/2-1 upward, lanes 128..223 sweep rows NZ-1..NZ/2
+    //     downward (the operator is mirror symmetric, so both use the same pivots), they meet in a
+    //     2x2 junction and substitute back outward.  y/x overwrite the column in place.
+    constexpr int HALF = NZ / 2;
+    const bool sw_up = tid < NX, sw_dn = (tid >= 128) && (tid < 128 + NX);
+    const int tj = sw_up ? tid : tid - 128;
+    const int tm = min(tj, NX - tj);
+    const double cpf = rdz * rdz * (double)NX * ((tm == 0 || tm == NX / 2) ? 1.0 : 2.0);   // cp_k = tab_k * cpf
+    double *col = lds + FB + mode_pos(tj) + (sw_up ? 0 : (NZ - 1) * RS);
+    const int cstr = sw_up ? RS : -RS;
+    if (sw_up || sw_dn) {
+        double y = 0.0;
+        constexpr int BLK = 8;
+        double rr[BLK], tt[BLK];
+#pragma unroll
+        for (int j = 0; j < BLK; ++j) { rr[j] = col[j * cstr]; tt[j] = tri_inv[j * G::NH + tm]; }
+#pragma unroll 1
+        for (int s0 = 0; s0 < HALF; s0 += BLK) {
+            double rn[BLK], tn[BLK];
+            const int sn = (s0 + BLK < HALF) ? s0 + BLK : s0;          // prefetch the next block (last: reload, unused)
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) { rn[j] = col[(sn + j) * cstr]; tn[j] = tri_inv[(sn + j) * G::NH + tm]; }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                y = rr[j] * tt[j] - (tt[j] * cpf) * y;
+                col[(s0 + j) * cstr] = y;
+            }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) { rr[j] = rn[j]; tt[j] = tn[j]; }
         }
-        double xr = 0.0, xi = 0.0;
-#pragma unroll 4
-        for (int p = NZ / 2 - 1; p >= 0; --p) {              // back substitution + repack
-            double *R = lds + (2 * p) * RS + FB, *I = R + RS;
-            const double cp1 = tri_inv[(2 * p + 1) * G::NH + m] * cpf, cp0 = tri_inv[(2 * p) * G::NH + m] * cpf;
-            const double y1r = I[q1], y1i = two ? I[q2] : 0.0;
-            const double y0r = R[q1], y0i = two ? R[q2] : 0.0;
-            const double x1r = y1r - cp1 * xr, x1i = y1i - cp1 * xi;     // row 2p+1
-            const double x0r = y0r - cp0 * x1r, x0i = y0i - cp0 * x1i;   // row 2p
-            xr = x0r; xi = x0i;
-            // Z[m] = A + iB, Z[N-m] = conj(A) + i conj(B)
-            R[q1] = x0r - x1i; I[q1] = x0i + x1r;
-            if (two) { R[q2] = x0r + x1i; I[q2] = x1r - x0i; }
+    }
+    __syncthreads();
+    STAMP(17);
+    if (sw_up || sw_dn) {
+        const double *mid = lds + FB + mode_pos(tj);
+        const double ya = mid[(HALF - 1) * RS], yb = mid[HALF * RS];
+        const double c = tri_inv[(HALF - 1) * G::NH + tm] * cpf;
+        const double jf = tri_inv[HALF * G::NH + tm];                 // 1/(1-c^2); 0 for the singular mean mode
+        double x = sw_up ? (ya - c * yb) * jf : (yb - c * ya) * jf;
+        if (tm == 0) x = sw_up ? ya : 0.0;                            // pin the mean mode (mean removed on output)
+        col[(HALF - 1) * cstr] = x;
+        constexpr int BLK = 8;
+#pragma unroll 1
+        for (int s0 = HALF - 2; s0 >= 0; s0 -= BLK) {
+            double yy[BLK], tt[BLK];
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                const int sidx = max(s0 - j, 0);
+                yy[j] = col[sidx * cstr]; tt[j] = tri_inv[sidx * G::NH + tm];
+            }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                if (s0 - j >= 0) {
+                    x = yy[j] - (tt[j] * cpf) * x;
+                    col[(s0 - j) * cstr] = x;
+                }
+            }
         }
+    }
+    __syncthreads();
+    STAMP(18);
+    // (3) repack: Z[m] = A + iB, Z[NX-m] = conj(A) + i conj(B)
+    for (int idx = tid; idx < (NX / 2 - 1) * (NZ / 2); idx += G::NT) {
+        const int p = idx / (NX / 2 - 1), m = 1 + idx - (NX / 2 - 1) * p;
+        const int q1 = mode_pos(m), q2 = mode_pos(NX - m);
+        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
+        const double are = R[q1], aim = R[q2], bre = I[q1], bim = I[q2];
+        R[q1] = are - bim; I[q1] = aim + bre;
+        R[q2] = are + bim; I[q2] = bre - aim;
     }
     __syncthreads();
     STAMP(9);
@@ -433,7 +480,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     const int env = blockIdx.x;
     if (P.mask && !P.mask[env]) return;
     const int tid = threadIdx.x;
-    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = 0;
 #if RBC_STAMPS
     if (tid == 0 || tid == (int)blockDim.x - 1) stamp_last = __builtin_amdgcn_s_memtime();
@@ -878,7 +925,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     STAMP(0);
 #if RBC_STAMPS
     if ((tid == 0 || tid == (int)blockDim.x - 1) && P.stamps)
-        for (int j = 0; j < 16; ++j) P.stamps[(size_t)env * 32 + (tid ? 16 : 0) + j] = stamp_acc[j];
+        for (int j = 0; j < 24; ++j) P.stamps[(size_t)env * 64 + (tid ? 32 : 0) + j] = stamp_acc[j];
 #endif
 }
 

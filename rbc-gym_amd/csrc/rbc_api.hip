@@ -69,23 +69,29 @@ void bind_kernel(rbc_handle *h)
     h->threads = rbc::Geo<NX, NZ>::NT;
 }
 
-// LU pivots of the z-direction operator of every Fourier mode (pressure solve):
+// Pivots of the z-direction operator of every Fourier mode (pressure solve):
 //   (phi[k-1] - 2 phi[k] + phi[k+1])/dz^2 - lam_x(m) phi[k] = r[k], mirror (Neumann) ends.
-// Stored as 1/(pivot*NX) so the unnormalised forward+inverse FFT pair needs no extra scaling.
+// The kernel eliminates from both walls at once (the operator is mirror symmetric), so only the
+// pivots of rows 0..nz/2-1 are needed: tab[k][m] = 1/(piv_k * nx * f_m), where nx undoes the
+// unnormalised FFT pair and f_m = 2 for the modes whose spectra come out of the row unpacking
+// doubled (1 for m = 0, nx/2).  Row nz/2 holds the junction factor 1/(1 - c^2), c = o/piv_{nz/2-1}
+// (0 for the singular mean mode m = 0, which the kernel pins instead).
 std::vector<double> tri_table(int nx, int nz, double lx, double lz)
 {
-    const int nh = nx / 2 + 1;
+    const int nh = nx / 2 + 1, half = nz / 2;
     const double dx = lx / nx, dz = lz / nz, o = 1.0 / (dz * dz), pi = 3.14159265358979323846;
-    std::vector<double> tab((size_t)nz * nh);
+    std::vector<double> tab((size_t)(half + 1) * nh);
     for (int m = 0; m < nh; ++m) {
         const double s = 2.0 * std::sin(m * pi / nx) / dx, lam = s * s;   // poisson_eigenvalues, Periodic
+        const double f = (m == 0 || m == nx / 2) ? 1.0 : 2.0;
         double piv = 0.0;
-        for (int k = 0; k < nz; ++k) {
-            double d = -((k == 0 || k == nz - 1) ? 1.0 : 2.0) * o - lam;
-            if (m == 0 && k == nz - 1) d -= o;   // pin the singular mean mode (mean removed on output)
+        for (int k = 0; k < half; ++k) {
+            const double d = -((k == 0) ? 1.0 : 2.0) * o - lam;
             piv = (k == 0) ? d : d - o * o / piv;
-            tab[(size_t)k * nh + m] = 1.0 / (piv * nx);
+            tab[(size_t)k * nh + m] = 1.0 / (piv * nx * f);
         }
+        const double c = o / piv;
+        tab[(size_t)half * nh + m] = (m == 0) ? 0.0 : 1.0 / (1.0 - c * c);
     }
     return tab;
 }
@@ -242,8 +248,8 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     CREATE_TRY(hipMalloc(&h->d_flags, B * sizeof(int)));
     CREATE_TRY(hipMemset(h->d_flags, 0, B * sizeof(int)));
 #if RBC_STAMPS
-    CREATE_TRY(hipMalloc(&h->d_stamps, B * 32 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(h->d_stamps, 0, B * 32 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&h->d_stamps, B * 64 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(h->d_stamps, 0, B * 64 * sizeof(unsigned long long)));
 #endif
     {
         std::vector<double> tab = tri_table(h->nx, h->nz, cfg->lx, cfg->lz);
@@ -560,7 +566,7 @@ int rbc_debug_stamps(rbc_handle *h, unsigned long long *out)
     if (!h->d_stamps || !out) return fail(RBC_ERR_INVALID, "not a stamp build");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(out, h->d_stamps, (size_t)h->B * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->d_stamps, (size_t)h->B * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RBC_OK;
 }
 

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rbc-gym_amd"))
 SO = os.path.join(ROOT, "rbc-gym_amd", "lib", "librbc_hip_stamps.so")
 NAMES = ["setup+outputs", "prepass barrier wait", "u tend", "b tend", "stash+w tend", "sync+write U*", "rhs", "fft A", "fft B",
-         "thomas", "ifft B", "ifft A", "correct", "b write", "loop top", "prepass compute"]
+         "pack", "ifft B", "ifft A", "correct", "b write", "loop top", "prepass compute", "unpack", "thomas fwd", "thomas jct+bwd", "-", "-", "-", "-", "-"]
 
 
 def build():
@@ -34,10 +34,10 @@ if __name__ == "__main__":
     act = np.random.default_rng(0).uniform(-1, 1, (B, 12)).astype(np.float32)
     for _ in range(2):
         sim.step(act)
-    st = np.zeros((B, 32), np.uint64)
+    st = np.zeros((B, 64), np.uint64)
     sim.lib.rbc_debug_stamps(sim.h, st.ctypes.data_as(C.POINTER(C.c_uint64)))
-    m0 = st[:, :16].astype(np.float64).mean(0)
-    m1 = st[:, 16:].astype(np.float64).mean(0)
+    m0 = st[:, :24].astype(np.float64).mean(0)
+    m1 = st[:, 32:56].astype(np.float64).mean(0)
     tot = m0.sum()
     print(f"mean cycles per env-step per workgroup: {tot:.0f}  ({tot / 150:.0f} per stage); first wave | last wave")
     for n, v, w in zip(NAMES, m0, m1):
