@@ -40,6 +40,9 @@ enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENC
 #ifndef RBC_STAMPS
 #define RBC_STAMPS 0
 #endif
+#ifndef RBC_EXPERIMENT_NOG0
+#define RBC_EXPERIMENT_NOG0 0   // timing experiment only (WRONG numerics): drops the G^- registers
+#endif
 #if RBC_STAMPS
 #define STAMP(id)                                                                                   \
     do {                                                                                            \
@@ -65,6 +68,7 @@ struct Params2D {
     double *nusselt;           // [B][2]
     int *flags;                // [B]
     double *dbg_g;             // [B][3][NZ][NX] (MODE_TENDENCY)
+    double *gpark;             // [B][2][NT][CZ]: previous-stage tendencies of b and w parked between stages
     unsigned long long *stamps; // [B][64] (RBC_STAMPS builds)
     double lx, lz, min_b, delta_b, heater_limit, kick;
     double dx, dz, rdx, rdz, rdx2, rdz2, rhz;   // uniform grid metrics (host-computed so they stay scalar-loadable)
@@ -237,6 +241,21 @@ struct Geo {
     static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
 };
 
+// Re-derive per-thread indices inside each phase instead of keeping dozens of loop-invariant
+// address registers alive across the whole stage loop (hipcc hoists them, runs out of VGPRs and
+// then spills/reloads them through scratch at ~1.5k cycles a reload): an empty volatile asm makes
+// the value opaque, so everything computed from it is rematerialised where it is used.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains the vector-memory queue
+// (s_waitcnt vmcnt(0)), which would expose the latency of the G^- prefetch loads and park stores
+// that are deliberately left in flight across phases; nothing inside the stage loop hands GLOBAL
+// data between threads, so waiting for this wave's LDS traffic is sufficient.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // position of Fourier mode m inside a transformed row (digit-reversed 8x12 order)
 __device__ __forceinline__ int mode_pos(int m) { return 12 * (m & 7) + (m >> 3); }
 
@@ -271,16 +290,19 @@ __device__ inline double block_sum(double v, double *scr, int tid)
 template <int NX, int NZ>
 __device__ __forceinline__ void project(double *__restrict__ lds, const double *__restrict__ tw,
                                         const double *__restrict__ tri_inv, double dts, double rdx, double rdz,
-                                        int tid, int i, int ip1, int im1, int k0, bool top,
-                                        unsigned long long *stamp_acc, unsigned long long &stamp_last)
+                                        int tid_in, unsigned long long *stamp_acc, unsigned long long &stamp_last)
 {
     using G = Geo<NX, NZ>;
     constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
     (void)stamp_acc; (void)stamp_last;
-    __syncthreads();
+    int tid = tid_in;
+    lds_barrier();
     STAMP(5);
+    tid = opaque(tid_in);
     // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl)
     {
+        const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, ip1 = (i + 1 == NX) ? 0 : i + 1;
+        const bool top = (c == G::NC - 1);
         const double rdt = 1.0 / dts;
         const double *me = lds + k0 * RS;
         double wlo = me[FW + i];
@@ -294,8 +316,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
             lds[(k0 + r) * RS + FB + i] = d;
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(6);
+    tid = opaque(tid_in);
     // ---- forward FFT along x, two rows (2p, 2p+1) packed as one complex sequence ----------
     if (tid < 12 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W96^(n2*k1)
         const int p = tid / 12, n2 = tid - 12 * p;
@@ -314,8 +337,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) { R[12 * k1 + n2] = re[k1]; I[12 * k1 + n2] = im[k1]; }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(7);
+    tid = opaque(tid_in);
     if (tid < 8 * (NZ / 2)) {           // pass B: DFT-12 over n2 for fixed k1 -> mode k1+8*k2 at 12*k1+k2
         const int p = tid / 8, k1 = tid - 8 * p;
         double *R = lds + (2 * p) * RS + FB + 12 * k1, *I = R + RS;
@@ -326,8 +350,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
 #pragma unroll
         for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(8);
+    tid = opaque(tid_in);
     // ---- z solve per wavenumber -------------------------------------------------------------
     // (1) unpack the row pairing in place: row 2p <- 2*spectrum of row 2p, row 2p+1 <- 2*spectrum of
     //     row 2p+1, each in half-complex form (Re of mode m at mode_pos(m), Im at mode_pos(NX-m));
@@ -340,8 +365,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         R[q1] = r1 + r2; R[q2] = i1 - i2;
         I[q1] = i1 + i2; I[q2] = r2 - r1;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(16);
+    tid = opaque(tid_in);
     // (2) the 96 real tridiagonal systems (one per half-complex column), each eliminated from BOTH
     //     walls at once: lanes 0..95 sweep rows 0..NZ/2-1 upward, lanes 128..223 sweep rows NZ-1..NZ/2
     //     downward (the operator is mirror symmetric, so both use the same pivots), they meet in a
@@ -374,7 +400,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
             for (int j = 0; j < BLK; ++j) { rr[j] = rn[j]; tt[j] = tn[j]; }
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(17);
     if (sw_up || sw_dn) {
         const double *mid = lds + FB + mode_pos(tj);
@@ -402,8 +428,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(18);
+    tid = opaque(tid_in);
     // (3) repack: Z[m] = A + iB, Z[NX-m] = conj(A) + i conj(B)
     for (int idx = tid; idx < (NX / 2 - 1) * (NZ / 2); idx += G::NT) {
         const int p = idx / (NX / 2 - 1), m = 1 + idx - (NX / 2 - 1) * p;
@@ -413,8 +440,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         R[q1] = are - bim; I[q1] = aim + bre;
         R[q2] = are + bim; I[q2] = bre - aim;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(9);
+    tid = opaque(tid_in);
     // ---- inverse FFT (swap re<->im roles) --------------------------------------------------
     if (tid < 8 * (NZ / 2)) {
         const int p = tid / 8, k1 = tid - 8 * p;
@@ -434,8 +462,9 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
 #pragma unroll
         for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(10);
+    tid = opaque(tid_in);
     if (tid < 12 * (NZ / 2)) {
         const int p = tid / 12, n2 = tid - 12 * p;
         double *R = lds + (2 * p) * RS + FB, *I = R + RS;
@@ -446,10 +475,12 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) { R[12 * n1 + n2] = re[n1]; I[12 * n1 + n2] = im[n1]; }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(11);
+    tid = opaque(tid_in);
     // ---- pressure_correct_velocities! ([OC] pressure_correction.jl) -------------------------
     {
+        const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, im1 = (i == 0) ? NX - 1 : i - 1;
         double *me = lds + k0 * RS;
         double pdn = (k0 > 0) ? me[-RS + FB + i] : 0.0;
 #pragma unroll
@@ -558,25 +589,29 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         for (int r = 0; r < CZ; ++r) bn[r] = me[r * RS + FB];
     }
 
-    double g0u[CZ], g0w[CZ], g0b[CZ];   // G^- (previous stage tendencies)
+    // G^- (previous stage tendencies).  Only G^-_u stays in registers across stages; G^-_b and
+    // G^-_w are parked in an L2-resident global workspace ([field][tid][8]: four 16-byte accesses
+    // per thread, a wave covers 4 KiB contiguously) and fetched back one pass ahead of their use, so
+    // their load latency hides under the preceding pass and the Poisson phases run with 32 fewer
+    // live VGPRs.
+    double g0u[CZ];
 #pragma unroll
-    for (int r = 0; r < CZ; ++r) { g0u[r] = 0.0; g0w[r] = 0.0; g0b[r] = 0.0; }
+    for (int r = 0; r < CZ; ++r) g0u[r] = 0.0;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    dbl2 *park_b = reinterpret_cast<dbl2 *>(P.gpark + (((size_t)env * 2 + 0) * G::NT + tid) * CZ);
+    dbl2 *park_w = reinterpret_cast<dbl2 *>(P.gpark + (((size_t)env * 2 + 1) * G::NT + tid) * CZ);
 
     const double rhz = P.rhz;   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
     const int nstage = (P.mode == MODE_STEP) ? 3 * P.nsub : ((P.mode == MODE_TENDENCY) ? 1 : 0);
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
         // set!'s incompressibility projection with unit time step ([OC] set_nonhydrostatic_model.jl)
-        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, i, ip1, im1, k0, top, stamp_acc, stamp_last);
+        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, stamp_acc, stamp_last);
         // the b slot now holds phi (pNHS); b stays in registers
     } else {
-        __syncthreads();
+        lds_barrier();
     }
 
-    // column addresses (doubles) of the 7-point x stencil, shared by all fields and rows
-    const double *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
-    const double *cc0 = lds + k0 * RS + i;
-    const double *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
     // row offset of (relative row rr, field f).  Rows outside the domain fall into the guard
     // rows / front scratch: whatever is read there is selected away by the wall-adjacent stencils
     auto off = [&](int rr, int f) -> int { return rr * RS + f; };
@@ -592,6 +627,16 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         const bool dbg = (P.mode == MODE_TENDENCY);
         double *dg = dbg ? P.dbg_g + (size_t)env * 3 * G::NCELL : nullptr;
         STAMP(14);
+        // column addresses of the 7-point x stencil, shared by all fields and rows; re-derived every
+        // stage (see opaque()) so they do not occupy registers through the Poisson phases
+        const int ti = opaque(tid);
+        const int c = ti / NX, i = ti - c * NX, k0 = c * CZ;
+        const bool bot = (c == 0), top = (c == G::NC - 1);
+        const int ip1 = (i + 1 == NX) ? 0 : i + 1, ip2 = (ip1 + 1 == NX) ? 0 : ip1 + 1, ip3 = (ip2 + 1 == NX) ? 0 : ip2 + 1;
+        const int im1 = (i == 0) ? NX - 1 : i - 1, im2 = (im1 == 0) ? NX - 1 : im1 - 1, im3 = (im2 == 0) ? NX - 1 : im2 - 1;
+        const double *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
+        const double *cc0 = lds + k0 * RS + i;
+        const double *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
 
         // ---- hydrostatic pressure anomaly ([OC] update_hydrostatic_pressure.jl) --------------
         // pHY'[k] = pHY'[k+1] - b_face(k+1) dz.  G_u needs pHY'[i,k]-pHY'[i-1,k]
@@ -615,8 +660,16 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             scr[c * NX + i] = acc;
         }
         STAMP(15);
-        __syncthreads();
+        const bool use_g0 = (ph != 0);      // zeta^1 = 0: the first stage of a substep needs no G^-
+        const bool keep_g = (ph != 2);      // the tendencies of the last stage are never reused
+        double g0b[CZ], g0w[CZ];
+        lds_barrier();
         STAMP(1);
+#pragma unroll
+        for (int r = 0; r < CZ; r += 2) {                                         // lands under the u pass
+            const dbl2 v = park_b[r / 2];
+            g0b[r] = use_g0 ? v.x : 0.0; g0b[r + 1] = use_g0 ? v.y : 0.0;
+        }
         double un[CZ], wn[CZ];
         // ======================= u tendency (walks down the chunk) ==============================
         {
@@ -672,14 +725,24 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 const double dphy = -(pacc + above) * dz;
                 const double g = vis - adv - dphy * rdx;
                 if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = g;
+#if RBC_EXPERIMENT_NOG0
+                un[r] = u0 + dt * (gam * g);
+#else
                 un[r] = u0 + dt * (gam * g + zet * g0u[r]);
+                asm volatile("" : "+v"(un[r]));   // pin the update here: hipcc otherwise sinks it past the Poisson solve
                 g0u[r] = g;
+#endif
                 fz_hi = fz_lo; uup = u0; wm_hi = wm_lo; wc_hi = wc_lo;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP(2);
         // ======================= b tendency (walks up) ===========================================
+#pragma unroll
+        for (int r = 0; r < CZ; r += 2) {                                         // lands under the b pass
+            const dbl2 v = park_w[r / 2];
+            g0w[r] = use_g0 ? v.x : 0.0; g0w[r + 1] = use_g0 ? v.y : 0.0;
+        }
         {
             double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
             w0 = cc0[off(-3, FB)]; w1 = cc0[off(-2, FB)]; w2 = cc0[off(-1, FB)];
@@ -708,17 +771,26 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * P.rdx2 + ((bup - b0) - (b0 - bdn)) * P.rdz2);
                 const double g = dif - adv;
                 if (dbg) dg[(k0 + r) * NX + i] = g;
+#if RBC_EXPERIMENT_NOG0
+                bn[r] = b0 + dt * (gam * g);
+#else
                 bn[r] = b0 + dt * (gam * g + zet * g0b[r]);
+                asm volatile("" : "+v"(bn[r]));
                 g0b[r] = g;
+#endif
                 fz_lo = fz_hi; bdn = b0;
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (keep_g) {
+#pragma unroll
+            for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0b[r]; v.y = g0b[r + 1]; park_b[r / 2] = v; }
         }
         STAMP(3);
         if (!dbg) {
             // every thread has finished reading the old b: its slot now parks the new u so that the
             // heaviest pass below runs with one new-value array fewer in registers
-            __syncthreads();
+            lds_barrier();
             double *me = lds + k0 * RS + i;
 #pragma unroll
             for (int r = 0; r < CZ; ++r) me[r * RS + FB] = un[r];
@@ -769,28 +841,37 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                     g = ((r == 0) && bot) ? 0.0 : (vis - adv);
                 }
                 if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = g;
+#if RBC_EXPERIMENT_NOG0
+                wn[r] = wc + dt * (gam * g);
+#else
                 wn[r] = wc + dt * (gam * g + zet * g0w[r]);
+                asm volatile("" : "+v"(wn[r]));
                 g0w[r] = g;
+#endif
                 fz_lo = fz_hi;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (dbg) return;
+        if (keep_g) {
+#pragma unroll
+            for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0w[r]; v.y = g0w[r + 1]; park_w[r / 2] = v; }
+        }
         STAMP(4);
-        __syncthreads();   // every read of the old state is done
+        lds_barrier();   // every read of the old state is done
         {
             double *me = lds + k0 * RS + i;
 #pragma unroll
             for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = me[r * RS + FB]; me[r * RS + FW] = wn[r]; }
         }
-        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, i, ip1, im1, k0, top, stamp_acc, stamp_last);
+        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last);
         STAMP(12);
         if (st + 1 < nstage) {
-            __syncthreads();   // phi reads done -> the b slot takes the new b
+            lds_barrier();   // phi reads done -> the b slot takes the new b
             double *me = lds + k0 * RS + i;
 #pragma unroll
             for (int r = 0; r < CZ; ++r) me[r * RS + FB] = bn[r];
-            __syncthreads();
+            lds_barrier();
         }
         STAMP(13);
     }

@@ -39,7 +39,7 @@ struct rbc_handle {
     int B = 0, nx = 0, nz = 0;
     size_t ncell = 0, env_stride = 0, obs_sz = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    double *d_fields = nullptr, *d_ra = nullptr, *d_tri = nullptr, *d_nu = nullptr, *d_dbg = nullptr;
+    double *d_fields = nullptr, *d_ra = nullptr, *d_tri = nullptr, *d_nu = nullptr, *d_dbg = nullptr, *d_park = nullptr;
     float *d_actions = nullptr, *d_obs = nullptr, *d_state = nullptr;
     uint8_t *d_mask = nullptr;
     uint64_t *d_seeds = nullptr;
@@ -110,6 +110,7 @@ rbc::Params2D base_params(const rbc_handle *h)
     p.nusselt = h->d_nu;
     p.flags = h->d_flags;
     p.dbg_g = h->d_dbg;
+    p.gpark = h->d_park;
     p.stamps = h->d_stamps;
     p.lx = h->cfg.lx; p.lz = h->cfg.lz;
     p.dx = h->cfg.lx / h->nx; p.dz = h->cfg.lz / h->nz;
@@ -245,6 +246,7 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     CREATE_TRY(hipMalloc(&h->d_obs, B * 5 * h->obs_sz * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->d_state, B * 5 * h->ncell * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->d_nu, B * 2 * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_park, B * 2 * rbc::CZ * (size_t)h->threads * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_flags, B * sizeof(int)));
     CREATE_TRY(hipMemset(h->d_flags, 0, B * sizeof(int)));
 #if RBC_STAMPS
@@ -274,7 +276,7 @@ int rbc_destroy(rbc_handle *h)
     if (!h) return RBC_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_actions, h->d_obs, h->d_state,
+    void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_park, h->d_actions, h->d_obs, h->d_state,
                     h->d_mask, h->d_seeds, h->d_flags, h->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
