@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="envs per GPU")
     ap.add_argument("--ra", type=float, default=1e4)
+    ap.add_argument("--ra-sweep", type=str, default=None,
+                    help="comma list, e.g. 1e4,1e5,1e6: BASELINE.json configs[3] stress case; the GLOBAL batch is split "
+                         "into contiguous equal parts, one Rayleigh number each (fixed dt=0.03 as in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,6 +110,11 @@ def main():
     sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)
     start, count = sharding.shard(world * B, world, rank)      # weak scaling: B envs on every GPU
     assert count == B
+    ra_env = None
+    if args.ra_sweep:
+        ras = [float(x) for x in args.ra_sweep.split(",")]
+        ra_env = np.array([ras[min(len(ras) - 1, (start + e) * len(ras) // (world * B))] for e in range(B)])
+        sim.set_rayleigh(ra_env)
     sim.reset(sharding.env_seeds(1234, start, count))
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
@@ -177,6 +185,10 @@ def main():
                                  "keeps the state in LDS for the whole control interval, so real HBM traffic is ~0.4 MB/env"},
             "cpu_baseline": cpu,
             "nan_envs": nan_total,
+            "ra_sweep": ({"values": [float(x) for x in args.ra_sweep.split(",")],
+                          "rank0_nan_envs_per_ra": {f"{r:g}": int(flags[ra_env == r].sum()) for r in sorted(set(ra_env))},
+                          "rank0_mean_nusselt_per_ra": {f"{r:g}": float(np.mean(nus[ra_env == r])) for r in sorted(set(ra_env))}}
+                         if args.ra_sweep else None),
             "mean_nusselt_state": float(np.mean(nus)),
         }
         print(json.dumps(out))

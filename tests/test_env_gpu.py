@@ -169,3 +169,34 @@ def test_full_batch_properties():
     for x, y in zip(out[:3], shifted[:3]):
         assert np.abs(np.roll(x, 8, axis=2) - y).max() < 1e-11
     assert np.abs(out[3] - shifted[3]).max() < 1e-10                          # Nusselt on the full state is shift invariant
+
+
+def test_rayleigh_sweep_statistics_match_reference_data(golden_dir):
+    """BASELINE.json configs[3] (stiff-dt stress) + pin P3: per-env Rayleigh numbers at the
+    reference's fixed dt=0.03; no NaNs, and the chaotic-regime kinetic energy / Nusselt statistics
+    land in the ranges spanned by the reference's checkpoint episodes (distributional pin only)."""
+    import json
+    from rbc_gym import _native
+    pins = json.load(open(os.path.join(golden_dir, "ckpt2d_pins.json")))
+    ras = [1e4, 1e5, 1e6]
+    per = 32
+    sim = _native.NativeSim(batch=per * len(ras))
+    sim.set_rayleigh(np.repeat(ras, per))
+    sim.reset(np.arange(per * len(ras), dtype=np.uint64) + 99)
+    zero = np.zeros((per * len(ras), 12), np.float32)
+    ke_hist = []
+    for n in range(200):                                   # t = 300: the reference samples its checkpoints at t = 600
+        assert sim.step(zero), "NaN at the reference's dt=0.03"
+        if n >= 150:
+            b, u, w = sim.get_fields()
+            ke_hist.append(0.5 * ((u ** 2).mean((1, 2)) + (w[:, :64] ** 2).mean((1, 2))))
+    assert sim.get_flags().sum() == 0
+    ke = np.mean(ke_hist, axis=0).reshape(len(ras), per)
+    nus, _ = sim.get_nusselt()
+    nus = nus.reshape(len(ras), per)
+    for j, ra in enumerate(ras):
+        eps = [e for sp in ("train", "val", "test") for e in pins[f"{sp}/ckpt_ra{int(ra)}"]["episodes"]]
+        ref_ke = np.array([e["ke"] for e in eps]); ref_nu = np.array([e["nusselt_state"] for e in eps])
+        assert abs(ke[j].mean() - ref_ke.mean()) < 0.12 * ref_ke.mean(), (ra, ke[j].mean(), ref_ke.mean())
+        lo, hi = ref_nu.min(), ref_nu.max()
+        assert lo - 0.25 * (hi - lo) - 0.2 < nus[j].mean() < hi + 0.25 * (hi - lo) + 0.2, (ra, nus[j].mean(), lo, hi)
