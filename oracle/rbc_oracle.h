@@ -91,6 +91,34 @@ double rbco_kinetic_energy(const rbco_sim *s);
 /* deterministic normal deviate shared by tests (hash of seed/field/index) */
 double rbco_normal(uint64_t seed, uint32_t field, uint32_t index);
 
+/* ---- 3D (rbc_oracle3d.c): restates rbc_sim3D.jl / rbc_sim3D_api.jl ------------------------------ */
+typedef struct rbco3_config {
+    int32_t nx, ny, nz;
+    double  lx, ly, lz;
+    double  ra, pr;
+    double  min_b, delta_b;
+    int32_t heaters;
+    double  heater_limit;
+    double  dt_solver;
+    double  dt_control;
+    double  random_kick;
+} rbco3_config;
+typedef struct rbco3_sim rbco3_sim;
+rbco3_sim *rbco3_create(const rbco3_config *cfg);
+void   rbco3_destroy(rbco3_sim *s);
+void   rbco3_reset_random(rbco3_sim *s, uint64_t seed);
+void   rbco3_reset_from_arrays(rbco3_sim *s, const double *b, const double *u, const double *v, const double *w);
+int    rbco3_step(rbco3_sim *s, const float *action);              /* action: heaters*heaters float32 */
+void   rbco3_set_action(rbco3_sim *s, const float *action, int raw_zero);
+void   rbco3_update_state(rbco3_sim *s);
+void   rbco3_substep(rbco3_sim *s, double dt);
+void   rbco3_get_fields(const rbco3_sim *s, double *b, double *u, double *v, double *w);
+void   rbco3_get_tendencies(const rbco3_sim *s, double *gu, double *gv, double *gw, double *gb);
+void   rbco3_get_state_f32(const rbco3_sim *s, float *out);
+double rbco3_nusselt(const rbco3_sim *s);
+void   rbco3_get_info(const rbco3_sim *s, double *t, int64_t *step);
+double rbco3_max_divergence(const rbco3_sim *s);
+
 #ifdef __cplusplus
 }
 #endif

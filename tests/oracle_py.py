@@ -24,8 +24,8 @@ class OracleConfig(C.Structure):
 
 
 def build_oracle(force=False):
-    src = os.path.join(ORACLE_DIR, "rbc_oracle.c")
-    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("rbc_oracle.c", "rbc_oracle3d.c", "rbc_oracle.h")]
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return ORACLE_SO
 
@@ -187,3 +187,117 @@ class OracleSim:
 
     def kinetic_energy(self):
         return self.L.rbco_kinetic_energy(self.h)
+
+
+# ---------------------------------------------------------------------------------------------
+# 3D oracle (oracle/rbc_oracle3d.c)
+# ---------------------------------------------------------------------------------------------
+class Oracle3Config(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("lx", C.c_double), ("ly", C.c_double), ("lz", C.c_double),
+                ("ra", C.c_double), ("pr", C.c_double), ("min_b", C.c_double), ("delta_b", C.c_double),
+                ("heaters", C.c_int32), ("heater_limit", C.c_double), ("dt_solver", C.c_double),
+                ("dt_control", C.c_double), ("random_kick", C.c_double)]
+
+
+_lib3_ready = False
+
+
+def lib3():
+    global _lib3_ready
+    L = lib()
+    if not _lib3_ready:
+        dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        L.rbco3_create.restype = C.c_void_p
+        L.rbco3_create.argtypes = [C.POINTER(Oracle3Config)]
+        L.rbco3_destroy.argtypes = [C.c_void_p]
+        L.rbco3_reset_random.argtypes = [C.c_void_p, C.c_uint64]
+        L.rbco3_reset_from_arrays.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.rbco3_step.restype = C.c_int
+        L.rbco3_step.argtypes = [C.c_void_p, fp]
+        L.rbco3_set_action.argtypes = [C.c_void_p, fp, C.c_int]
+        L.rbco3_update_state.argtypes = [C.c_void_p]
+        L.rbco3_substep.argtypes = [C.c_void_p, C.c_double]
+        L.rbco3_get_fields.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.rbco3_get_tendencies.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.rbco3_get_state_f32.argtypes = [C.c_void_p, fp]
+        L.rbco3_nusselt.restype = C.c_double
+        L.rbco3_nusselt.argtypes = [C.c_void_p]
+        L.rbco3_get_info.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
+        L.rbco3_max_divergence.restype = C.c_double
+        L.rbco3_max_divergence.argtypes = [C.c_void_p]
+        _lib3_ready = True
+    return L
+
+
+class Oracle3D:
+    """One 3D env on the CPU oracle (rbc_sim3D_api.jl semantics; shapes (nz, ny, nx))."""
+
+    def __init__(self, ra=2500.0, shape=(16, 32, 32), domain=(2.0, 4 * np.pi, 4 * np.pi), heaters=8, heater_limit=0.9,
+                 dt_control=0.125, dt_solver=0.01, pr=0.7, t_diff=(1.0, 2.0), kick=0.01):
+        nz, ny, nx = shape
+        lz, ly, lx = domain
+        self.cfg = Oracle3Config(nx, ny, nz, lx, ly, lz, float(ra), pr, t_diff[0], t_diff[1] - t_diff[0], heaters,
+                                 heater_limit, dt_solver, dt_control, kick)
+        self.L = lib3()
+        self.h = C.c_void_p(self.L.rbco3_create(C.byref(self.cfg)))
+        if not self.h:
+            raise RuntimeError("rbco3_create failed")
+        self.nx, self.ny, self.nz, self.heaters = nx, ny, nz, heaters
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.rbco3_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def reset_random(self, seed):
+        self.L.rbco3_reset_random(self.h, int(seed))
+
+    def reset_from_arrays(self, b, u, v, w):
+        a = [np.ascontiguousarray(x, np.float64) for x in (b, u, v, w)]
+        assert a[0].shape == (self.nz, self.ny, self.nx) and a[3].shape == (self.nz + 1, self.ny, self.nx)
+        self.L.rbco3_reset_from_arrays(self.h, *[_dp(x) for x in a])
+
+    def step(self, action=None):
+        a = np.zeros((self.heaters, self.heaters), np.float32) if action is None else np.ascontiguousarray(action, np.float32)
+        return bool(self.L.rbco3_step(self.h, _fp(a)))
+
+    def set_action(self, action):
+        a = np.ascontiguousarray(action, np.float32)
+        self.L.rbco3_set_action(self.h, _fp(a), 0)
+
+    def update_state(self):
+        self.L.rbco3_update_state(self.h)
+
+    def substep(self, dt):
+        self.L.rbco3_substep(self.h, float(dt))
+
+    def fields(self):
+        s = (self.nz, self.ny, self.nx)
+        b, u, v, w = np.empty(s), np.empty(s), np.empty(s), np.empty((self.nz + 1, self.ny, self.nx))
+        self.L.rbco3_get_fields(self.h, _dp(b), _dp(u), _dp(v), _dp(w))
+        return b, u, v, w
+
+    def tendencies(self):
+        g = [np.empty((self.nz, self.ny, self.nx)) for _ in range(4)]
+        self.L.rbco3_get_tendencies(self.h, *[_dp(x) for x in g])
+        return dict(u=g[0], v=g[1], w=g[2], b=g[3])
+
+    def state(self):
+        o = np.empty((4, self.nz, self.ny, self.nx), np.float32)
+        self.L.rbco3_get_state_f32(self.h, _fp(o))
+        return o
+
+    def nusselt(self):
+        return self.L.rbco3_nusselt(self.h)
+
+    def info(self):
+        t, s = C.c_double(), C.c_int64()
+        self.L.rbco3_get_info(self.h, C.byref(t), C.byref(s))
+        return t.value, s.value
+
+    def max_divergence(self):
+        return self.L.rbco3_max_divergence(self.h)
