@@ -47,7 +47,8 @@ enum {
    hard-codes (:28-38).  Shapes are in the reference's Julia order (x, z). */
 typedef struct rbc_config {
     int32_t abi_version;     /* = RBC_ABI_VERSION                                            */
-    int32_t dim;             /* 2 (3 reserved)                                               */
+    int32_t dim;             /* 2, or 3 (rbc_sim3D_api.jl: grid (nx,ny,nz), L (lx,ly,lz), heaters x heaters
+                                actions, dt_* in free-fall units scaled by t_ff = lz^2, 4 channels b,u,v,w) */
     int32_t nx, ny, nz;      /* grid = state_shape[::-1]  (96, 1, 64)                        */
     double  lx, ly, lz;      /* L = [2*pi, 2]                                   (api:28)     */
     double  ra;              /* default Rayleigh number for every env            (api:17)     */
@@ -90,7 +91,14 @@ int  rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds);
 int  rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask,
                            const double *b, const double *u, const double *w);
 
-/* step_simulation (api:75-97): actions [B][heaters] float32 in [-1,1] (host pointer).
+/* 3D variants (initialize_from_checkpoint rbc_sim3D.jl:181-199; get_state rbc_sim3D_api.jl:106-121):
+   b,u,v: [B][nz][ny][nx], w: [B][nz+1][ny][nx] float64                                      */
+int  rbc_reset_from_arrays3(rbc_handle *h, const uint8_t *mask,
+                            const double *b, const double *u, const double *v, const double *w);
+int  rbc_get_fields3(rbc_handle *h, double *b, double *u, double *v, double *w);
+
+/* step_simulation (api:75-97): actions [B][heaters] float32 in [-1,1] (host pointer;
+   dim=3: [B][heaters][heaters], preprocess_action rbc_sim3D.jl:111-128 is applied on the device).
    Advances every env by dt_control. Returns RBC_OK, or RBC_ERR_NAN if any env has NaNs.   */
 int  rbc_step(rbc_handle *h, const float *actions);
 int  rbc_step_dev(rbc_handle *h, const float *actions_dev);  /* async on the handle's stream */
@@ -130,6 +138,7 @@ double rbc_algorithmic_bytes_per_env_step(rbc_handle *h);
 /* operator-level test hooks (used by the parity tests only; not needed by the env layer):
    tendencies G(b,u,w) of the current state for the given actions: gb,gu,gw [B][nz][nx]    */
 int  rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw);
+int  rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, double *gv, double *gw, double *gb);
 /* run `nsub` RK3 substeps of size dt with the given actions (no counters touched)          */
 int  rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt);
 /* diagnostic builds only (-DRBC_STAMPS=1): per-phase shader-clock cycles of the last launch,

@@ -1,0 +1,173 @@
+// rbc3d_host.hpp -- host side of the 3D path (included by rbc_api.hip after `struct rbc_handle`).
+// Replaces rbc_sim3D_api.jl (initialize_simulation :17, step_simulation :77, get_state :106,
+// get_info :126, get_nusselt :134) for a batch of envs; see rbc3d_kernels.hpp for the launch sequence.
+#pragma once
+#include "rbc3d_kernels.hpp"
+
+struct rbc3_state {
+    rbc3::Geo3 g;
+    rbc3::FftPlan plan;
+    double *st[2] = {nullptr, nullptr};   // ping-pong state buffers [B][b|u|v|w]
+    int cur = 0;
+    double *gm = nullptr, *phy = nullptr, *phi = nullptr, *tab = nullptr, *actT = nullptr, *dbg = nullptr;
+    double2 *spec = nullptr;
+    size_t fft_lds = 0;
+    double tff = 1.0;
+};
+
+namespace {
+
+void factor2(int n, int &n1, int &n2)
+{
+    n1 = 1;
+    for (int d = 1; d * d <= n; ++d)
+        if (n % d == 0) n1 = d;
+    n2 = n / n1;
+}
+
+#define HIP3(expr)                                                                                 \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(RBC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int create3d(rbc_handle *h)
+{
+    const rbc_config &c = h->cfg;
+    auto *s = new rbc3_state();
+    h->s3 = s;
+    rbc3::Geo3 &g = s->g;
+    g.nx = c.nx; g.ny = c.ny; g.nz = c.nz;
+    g.nc = c.nx * c.ny * c.nz; g.nw = c.nx * c.ny * (c.nz + 1);
+    g.env_stride = (size_t)3 * g.nc + g.nw;
+    g.lx = c.lx; g.ly = c.ly; g.lz = c.lz;
+    g.dx = c.lx / c.nx; g.dy = c.ly / c.ny; g.dz = c.lz / c.nz;
+    g.rdx = 1.0 / g.dx; g.rdy = 1.0 / g.dy; g.rdz = 1.0 / g.dz;
+    g.min_b = c.min_b; g.delta_b = c.delta_b; g.heater_limit = c.heater_limit; g.kick = c.random_kick;
+    g.heaters = c.heaters;
+    s->tff = c.lz * c.lz;                                    // rbc_sim3D_api.jl:43
+    factor2(c.nx, s->plan.nx1, s->plan.nx2);
+    factor2(c.ny, s->plan.ny1, s->plan.ny2);
+    s->fft_lds = ((size_t)2 * c.nx * c.ny + c.nx + c.ny) * sizeof(double2);
+    if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
+    const size_t B = h->B;
+    for (int q = 0; q < 2; ++q) {
+        HIP3(hipMalloc(&s->st[q], B * g.env_stride * sizeof(double)));
+        HIP3(hipMemset(s->st[q], 0, B * g.env_stride * sizeof(double)));
+    }
+    HIP3(hipMalloc(&s->gm, B * g.env_stride * sizeof(double)));
+    HIP3(hipMemset(s->gm, 0, B * g.env_stride * sizeof(double)));
+    HIP3(hipMalloc(&s->phy, B * (size_t)g.nc * sizeof(double)));
+    HIP3(hipMalloc(&s->phi, B * (size_t)g.nc * sizeof(double)));
+    HIP3(hipMalloc(&s->spec, B * (size_t)g.nc * sizeof(double2)));
+    HIP3(hipMalloc(&s->actT, B * (size_t)c.heaters * c.heaters * sizeof(double)));
+    HIP3(hipMemset(s->actT, 0, B * (size_t)c.heaters * c.heaters * sizeof(double)));
+    {   // pivots of the z operator for every horizontal mode: tab[k][n][m] = 1/piv_k
+        const double o = 1.0 / (g.dz * g.dz), pi = 3.14159265358979323846;
+        std::vector<double> tab((size_t)g.nc);
+        for (int n = 0; n < c.ny; ++n)
+            for (int m = 0; m < c.nx; ++m) {
+                const double tx = 2.0 * std::sin(m * pi / c.nx) / g.dx, ty = 2.0 * std::sin(n * pi / c.ny) / g.dy;
+                const double lam = tx * tx + ty * ty;
+                double piv = 0.0;
+                for (int k = 0; k < c.nz; ++k) {
+                    double d = -((k == 0 || k == c.nz - 1) ? 1.0 : 2.0) * o - lam;
+                    if (m == 0 && n == 0 && k == c.nz - 1) d -= o;       // pin the singular mean mode
+                    piv = (k == 0) ? d : d - o * o / piv;
+                    tab[((size_t)k * c.ny + n) * c.nx + m] = 1.0 / piv;
+                }
+            }
+        HIP3(hipMalloc(&s->tab, tab.size() * sizeof(double)));
+        HIP3(hipMemcpy(s->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
+    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_ifft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
+    return RBC_OK;
+}
+
+void destroy3d(rbc_handle *h)
+{
+    rbc3_state *s = h->s3;
+    if (!s) return;
+    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->actT, s->tab, s->dbg};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete s;
+    h->s3 = nullptr;
+}
+
+inline dim3 grid_for(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// exact projection of state buffer `buf` with stage step dts (mask: device pointer or null)
+int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
+{
+    rbc3_state *s = h->s3;
+    const rbc3::Geo3 &g = s->g;
+    const int B = h->B;
+    hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
+    hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, s->spec, s->tab, B);
+    hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
+    hipLaunchKernelGGL(rbc3::k3_correct, grid_for((size_t)B * g.nc, 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
+    HIP3(hipGetLastError());
+    return RBC_OK;
+}
+
+int output3d(rbc_handle *h, const uint8_t *mask)
+{
+    rbc3_state *s = h->s3;
+    hipLaunchKernelGGL(rbc3::k3_output, dim3(h->B), dim3(256), 0, h->stream, s->g, s->st[s->cur], h->d_ra, h->d_state, h->d_nu, h->d_flags, mask);
+    HIP3(hipGetLastError());
+    return RBC_OK;
+}
+
+// one stage list for `nsub` substeps (the last of size dt_last); actions already on the device
+int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last)
+{
+    rbc3_state *s = h->s3;
+    const rbc3::Geo3 &g = s->g;
+    const int B = h->B;
+    hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(B), dim3(64), 0, h->stream, g, actions_dev, s->actT, 0);
+    const double gam[3] = {8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0}, zet[3] = {0.0, -17.0 / 60.0, -5.0 / 12.0};
+    const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
+    for (int n = 0; n < nsub; ++n) {
+        const double d = (n == nsub - 1) ? dt_last : dt;
+        for (int ph = 0; ph < 3; ++ph) {
+            double *cur = s->st[s->cur], *nxt = s->st[s->cur ^ 1];
+            hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
+            hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            if (int rc = project3d(h, nxt, (gam[ph] + zet[ph]) * d, nullptr)) return rc;
+            s->cur ^= 1;
+        }
+    }
+    HIP3(hipGetLastError());
+    return RBC_OK;
+}
+
+int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last, bool timed)
+{
+    const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
+    if (rec) HIP3(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
+    if (int rc = advance3d(h, actions_dev, nsub, dt, dt_last)) return rc;
+    if (int rc = output3d(h, nullptr)) return rc;
+    if (rec) {
+        HIP3(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
+        h->ev_used++;
+    }
+    return RBC_OK;
+}
+
+// finish a reset of the masked envs: set!'s projection with unit step + outputs
+int finish_reset3d(rbc_handle *h)
+{
+    rbc3_state *s = h->s3;
+    hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(h->B), dim3(64), 0, h->stream, s->g, (const float *)nullptr, s->actT, 1);
+    if (int rc = project3d(h, s->st[s->cur], 1.0, h->d_mask)) return rc;
+    if (int rc = output3d(h, h->d_mask)) return rc;
+    HIP3(hipStreamSynchronize(h->stream));
+    return RBC_OK;
+}
+
+}  // namespace

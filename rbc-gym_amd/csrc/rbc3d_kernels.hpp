@@ -1,0 +1,457 @@
+// rbc3d_kernels.hpp -- streaming 3D Boussinesq integrator for gfx950 (first, correctness-first cut).
+//
+// Replaces `step_simulation`/`initialize_simulation` of src/rbc_gym/sim/rbc_sim3D_api.jl (77-101,
+// 17-72) for a batch of envs.  A 3D env (32x48x48: 2.4 MB of fp64 state) does not fit one CU's LDS,
+// so unlike the 2D kernel the state lives in HBM/L2 (32 envs = 75 MB, resident in the 256 MB
+// Infinity Cache) and every RK3 stage is a short sequence of launches:
+//   hydrostatic scan -> 4 tendency kernels (one thread per cell, plain cached loads) writing U* into
+//   the other state buffer -> per-z-slab 2D FFT in LDS -> per-(kx,ky) tridiagonal sweep -> inverse
+//   FFT -> projection.
+// Same discretisation as the 2D kernel; layouts [k][j][i].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rbc2d_kernel.hpp"   // normal_deviate, stencil helpers
+
+namespace rbc3 {
+
+using rbc::left3; using rbc::left5; using rbc::right3; using rbc::right5; using rbc::sym4;
+
+struct Geo3 {
+    int nx, ny, nz;
+    int nc;            // nx*ny*nz
+    int nw;            // nx*ny*(nz+1)
+    size_t env_stride; // doubles per env in one state buffer: b,u,v (nc each) + w (nw)
+    double dx, dy, dz, rdx, rdy, rdz, lx, ly, lz;
+    double min_b, delta_b, heater_limit, kick;
+    int heaters;
+};
+
+__device__ __forceinline__ double upw(double vel, double L, double R) { return vel * (vel > 0.0 ? L : R); }
+
+// periodic 7-point index table around i
+__device__ __forceinline__ void wrap7(int i, int n, int *o)
+{
+#pragma unroll
+    for (int d = -3; d <= 3; ++d) { int t = i + d; t += (t < 0) ? n : 0; t -= (t >= n) ? n : 0; o[d + 3] = t; }
+}
+
+// z (Bounded, N cells).  centre field -> face k: p[j] = psi[k-3+j], j=0..5 (face between p[2] | p[3])
+__device__ __forceinline__ double zfL(const double *p, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 4 && k1 <= N - 2) ? left5(p[0], p[1], p[2], p[3], p[4]) : ((k1 >= 3 && k1 <= N - 1) ? left3(p[1], p[2], p[3]) : p[2]); }
+__device__ __forceinline__ double zfR(const double *p, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 4 && k1 <= N - 2) ? right5(p[1], p[2], p[3], p[4], p[5]) : ((k1 >= 3 && k1 <= N - 1) ? right3(p[2], p[3], p[4]) : p[3]); }
+__device__ __forceinline__ double zfS(const double *p, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 4 && k1 <= N - 2) ? sym4(p[1], p[2], p[3], p[4]) : 0.5 * (p[2] + p[3]); }
+// face field -> centre k: p[j] = psi_face[k-2+j], j=0..5 (centre between p[2] | p[3])
+__device__ __forceinline__ double zcL(const double *p, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 3 && k1 <= N - 2) ? left5(p[0], p[1], p[2], p[3], p[4]) : ((k1 >= 2 && k1 <= N - 1) ? left3(p[1], p[2], p[3]) : p[2]); }
+__device__ __forceinline__ double zcR(const double *p, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 3 && k1 <= N - 2) ? right5(p[1], p[2], p[3], p[4], p[5]) : ((k1 >= 2 && k1 <= N - 1) ? right3(p[2], p[3], p[4]) : p[3]); }
+__device__ __forceinline__ double zcS(const double *p, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 3 && k1 <= N - 2) ? sym4(p[1], p[2], p[3], p[4]) : 0.5 * (p[2] + p[3]); }
+
+__device__ __forceinline__ double l5a(const double *p) { return left5(p[0], p[1], p[2], p[3], p[4]); }
+__device__ __forceinline__ double r5a(const double *p) { return right5(p[1], p[2], p[3], p[4], p[5]); }
+
+// accessor of one env's state buffer
+struct Fields {
+    const double *b, *u, *v, *w;
+    int nx, ny, nz;
+    __device__ __forceinline__ size_t at(int i, int j, int k) const { return ((size_t)k * ny + j) * nx + i; }
+};
+
+// wall temperature of column (i,j): bottom_T, rbc_sim3D.jl:131-141 (act = preprocessed 8x8 table)
+__device__ __forceinline__ double bottom_T(const Geo3 &g, const double *act, int i, int j)
+{
+    const int n = g.heaters;
+    const double x = (i + 0.5) * g.dx, y = (j + 0.5) * g.dy;
+    int a = (int)floor(x / g.lx * n) + 1, c = (int)floor(y / g.ly * n) + 1;
+    a = min(max(a, 1), n); c = min(max(c, 1), n);
+    return act[(a - 1) * n + (c - 1)];
+}
+
+// ---- preprocess_action, rbc_sim3D.jl:111-128: act_T[env][n*n] -----------------------------------
+__global__ void k3_preprocess(Geo3 g, const float *actions, double *actT, int raw_zero)
+{
+    const int env = blockIdx.x, nn = g.heaters * g.heaters;
+    if (threadIdx.x != 0) return;
+    double *o = actT + (size_t)env * nn;
+    if (raw_zero || actions == nullptr) { for (int a = 0; a < nn; ++a) o[a] = 0.0; return; }
+    const float *in = actions + (size_t)env * nn;
+    double mean = 0.0, mx = 0.0;
+    for (int a = 0; a < nn; ++a) mean += (double)in[a];
+    mean /= nn;
+    for (int a = 0; a < nn; ++a) mx = fmax(mx, fabs((double)in[a] - mean));
+    const double K = mx > 1.0 ? mx : 1.0;
+    for (int a = 0; a < nn; ++a) o[a] = (g.min_b + g.delta_b) + (((double)in[a] - mean) / K) * g.heater_limit;
+}
+
+// ---- hydrostatic pressure anomaly: thread per column --------------------------------------------
+__global__ void k3_hydrostatic(Geo3 g, const double *state, double *phy, int B)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = g.nx * g.ny;
+    if (col >= ncol * B) return;
+    const int env = col / ncol, ij = col - env * ncol;
+    const double *b = state + (size_t)env * g.env_stride;
+    double *p = phy + (size_t)env * g.nc;
+    const double hz = g.dz / 2;
+    const double cN = b[(size_t)(g.nz - 1) * ncol + ij];
+    const double halo = cN + ((g.min_b - cN) / hz) * g.dz;
+    double acc = -(0.5 * (cN + halo)) * g.dz;
+    p[(size_t)(g.nz - 1) * ncol + ij] = acc;
+    double up = cN;
+    for (int k = g.nz - 2; k >= 0; --k) {
+        const double c = b[(size_t)k * ncol + ij];
+        acc = acc - (0.5 * (c + up)) * g.dz;
+        p[(size_t)k * ncol + ij] = acc;
+        up = c;
+    }
+}
+
+// ---- tendencies + RK update; FIELD 0:u 1:v 2:w 3:b ------------------------------------------------
+// cur: state read; nxt: U* written; gm: G^- read / G written (same layout as the state buffer).
+template <int FIELD>
+__global__ void k3_tendency(Geo3 g, const double *cur, double *nxt, double *gm, const double *phy, const double *actT,
+                            const double *nu_kappa, double dt, double gam, double zet, int B, double *dbg)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= g.nc * B) return;
+    const int env = cell / g.nc, c0 = cell - env * g.nc;
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const int k = c0 / (nx * ny), j = (c0 - k * nx * ny) / nx, i = c0 - (k * ny + j) * nx;
+    const double *sb = cur + (size_t)env * g.env_stride;
+    const double *b = sb, *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double nu = nu_kappa[2 * env], ka = nu_kappa[2 * env + 1];
+    const double rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
+    int xi[7], yj[7];
+    wrap7(i, nx, xi); wrap7(j, ny, yj);
+    const int pl = nx * ny;
+    auto A = [&](const double *f, int a, int bb, int kk) -> double { return f[(size_t)kk * pl + yj[bb + 3] * nx + xi[a + 3]]; };
+    // z access with clamping (values read outside the domain are never used) for centre fields
+    auto Zc = [&](const double *f, int a, int bb, int kk) -> double { return A(f, a, bb, min(max(kk, 0), nz - 1)); };
+    // w has nz+1 levels; beyond the walls -> clamp (unused)
+    auto Zw = [&](int a, int bb, int kk) -> double { return A(w, a, bb, min(max(kk, 0), nz)); };
+    // ghost values of the Value BCs (no-slip for u,v; plate temperatures for b)
+    auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
+    auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
+
+    double G;
+    double old;
+    if (FIELD == 0) {
+        // ---- u at (x-face i, j, k) ----
+        double p[6];
+        // flux_uu at centres i-1 and i
+        double fe, fw;
+        { double q[6]; for (int t = 0; t < 6; ++t) q[t] = A(u, t - 2, 0, k); fe = upw(sym4(q[1], q[2], q[3], q[4]), l5a(q), r5a(q)); }
+        { double q[6]; for (int t = 0; t < 6; ++t) q[t] = A(u, t - 3, 0, k); fw = upw(sym4(q[1], q[2], q[3], q[4]), l5a(q), r5a(q)); }
+        // flux_vu at (xf i, yf j+1) and (xf i, yf j): v interpolated in x, u biased in y
+        double fn, fs;
+        { const double vt = sym4(A(v, -2, 1, k), A(v, -1, 1, k), A(v, 0, 1, k), A(v, 1, 1, k));
+          for (int t = 0; t < 6; ++t) p[t] = A(u, 0, t - 2, k); fn = upw(vt, l5a(p), r5a(p)); }
+        { const double vt = sym4(A(v, -2, 0, k), A(v, -1, 0, k), A(v, 0, 0, k), A(v, 1, 0, k));
+          for (int t = 0; t < 6; ++t) p[t] = A(u, 0, t - 3, k); fs = upw(vt, l5a(p), r5a(p)); }
+        // flux_wu at (xf i, zf k+1) and (xf i, zf k)
+        double ft = 0.0, fb = 0.0;
+        if (k + 1 < nz) { const double wt = sym4(Zw(-2, 0, k + 1), Zw(-1, 0, k + 1), Zw(0, 0, k + 1), Zw(1, 0, k + 1));
+                          for (int t = 0; t < 6; ++t) p[t] = Zc(u, 0, 0, k - 2 + t); ft = upw(wt, zfL(p, k + 1, nz), zfR(p, k + 1, nz)); }
+        if (k > 0) { const double wt = sym4(Zw(-2, 0, k), Zw(-1, 0, k), Zw(0, 0, k), Zw(1, 0, k));
+                     for (int t = 0; t < 6; ++t) p[t] = Zc(u, 0, 0, k - 3 + t); fb = upw(wt, zfL(p, k, nz), zfR(p, k, nz)); }
+        const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
+        const double u0 = A(u, 0, 0, k);
+        const double uup = (k + 1 < nz) ? A(u, 0, 0, k + 1) : ghost_hi(u0, 0.0);
+        const double udn = (k > 0) ? A(u, 0, 0, k - 1) : ghost_lo(u0, 0.0);
+        const double dwt = (k + 1 < nz) ? (Zw(0, 0, k + 1) - Zw(-1, 0, k + 1)) : 0.0;
+        const double dwb = (k > 0) ? (Zw(0, 0, k) - Zw(-1, 0, k)) : 0.0;
+        const double vis = nu * (2.0 * ((A(u, 1, 0, k) - u0) - (u0 - A(u, -1, 0, k))) * rdx * rdx
+                                 + (((A(u, 0, 1, k) - u0) * rdy + (A(v, 0, 1, k) - A(v, -1, 1, k)) * rdx)
+                                    - ((u0 - A(u, 0, -1, k)) * rdy + (A(v, 0, 0, k) - A(v, -1, 0, k)) * rdx)) * rdy
+                                 + (((uup - u0) * rdz + dwt * rdx) - ((u0 - udn) * rdz + dwb * rdx)) * rdz);
+        const double *ph = phy + (size_t)env * g.nc;
+        G = vis - adv - (A(ph, 0, 0, k) - A(ph, -1, 0, k)) * rdx;
+        old = u0;
+    } else if (FIELD == 1) {
+        // ---- v at (i, y-face j, k): mirror of u with x<->y ----
+        double p[6];
+        double fe, fw;   // flux_uv at (xf i+1, yf j) and (xf i, yf j): u interpolated in y, v biased in x
+        { const double ut = sym4(A(u, 1, -2, k), A(u, 1, -1, k), A(u, 1, 0, k), A(u, 1, 1, k));
+          for (int t = 0; t < 6; ++t) p[t] = A(v, t - 2, 0, k); fe = upw(ut, l5a(p), r5a(p)); }
+        { const double ut = sym4(A(u, 0, -2, k), A(u, 0, -1, k), A(u, 0, 0, k), A(u, 0, 1, k));
+          for (int t = 0; t < 6; ++t) p[t] = A(v, t - 3, 0, k); fw = upw(ut, l5a(p), r5a(p)); }
+        double fn, fs;   // flux_vv at centres j and j-1
+        { double q[6]; for (int t = 0; t < 6; ++t) q[t] = A(v, 0, t - 2, k); fn = upw(sym4(q[1], q[2], q[3], q[4]), l5a(q), r5a(q)); }
+        { double q[6]; for (int t = 0; t < 6; ++t) q[t] = A(v, 0, t - 3, k); fs = upw(sym4(q[1], q[2], q[3], q[4]), l5a(q), r5a(q)); }
+        double ft = 0.0, fb = 0.0;
+        if (k + 1 < nz) { const double wt = sym4(Zw(0, -2, k + 1), Zw(0, -1, k + 1), Zw(0, 0, k + 1), Zw(0, 1, k + 1));
+                          for (int t = 0; t < 6; ++t) p[t] = Zc(v, 0, 0, k - 2 + t); ft = upw(wt, zfL(p, k + 1, nz), zfR(p, k + 1, nz)); }
+        if (k > 0) { const double wt = sym4(Zw(0, -2, k), Zw(0, -1, k), Zw(0, 0, k), Zw(0, 1, k));
+                     for (int t = 0; t < 6; ++t) p[t] = Zc(v, 0, 0, k - 3 + t); fb = upw(wt, zfL(p, k, nz), zfR(p, k, nz)); }
+        const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
+        const double v0 = A(v, 0, 0, k);
+        const double vup = (k + 1 < nz) ? A(v, 0, 0, k + 1) : ghost_hi(v0, 0.0);
+        const double vdn = (k > 0) ? A(v, 0, 0, k - 1) : ghost_lo(v0, 0.0);
+        const double dwt = (k + 1 < nz) ? (Zw(0, 0, k + 1) - Zw(0, -1, k + 1)) : 0.0;
+        const double dwb = (k > 0) ? (Zw(0, 0, k) - Zw(0, -1, k)) : 0.0;
+        const double vis = nu * ((((A(u, 1, 0, k) - A(u, 1, -1, k)) * rdy + (A(v, 1, 0, k) - v0) * rdx)
+                                  - ((A(u, 0, 0, k) - A(u, 0, -1, k)) * rdy + (v0 - A(v, -1, 0, k)) * rdx)) * rdx
+                                 + 2.0 * ((A(v, 0, 1, k) - v0) - (v0 - A(v, 0, -1, k))) * rdy * rdy
+                                 + (((vup - v0) * rdz + dwt * rdy) - ((v0 - vdn) * rdz + dwb * rdy)) * rdz);
+        const double *ph = phy + (size_t)env * g.nc;
+        G = vis - adv - (A(ph, 0, 0, k) - A(ph, 0, -1, k)) * rdy;
+        old = v0;
+    } else if (FIELD == 2) {
+        // ---- w at (i, j, z-face k); wall face k=0 never evolves ----
+        const double w0 = A(w, 0, 0, k);
+        old = w0;
+        if (k == 0) { G = 0.0; }
+        else {
+            double p[6], q[6];
+            double fe, fw, fn, fs;
+            // flux_uw: u interpolated in z to face k (at x-faces i+1 and i), w biased in x
+            for (int t = 0; t < 6; ++t) q[t] = Zc(u, 1, 0, k - 3 + t);
+            for (int t = 0; t < 6; ++t) p[t] = A(w, t - 2, 0, k);
+            fe = upw(zfS(q, k, nz), l5a(p), r5a(p));
+            for (int t = 0; t < 6; ++t) q[t] = Zc(u, 0, 0, k - 3 + t);
+            for (int t = 0; t < 6; ++t) p[t] = A(w, t - 3, 0, k);
+            fw = upw(zfS(q, k, nz), l5a(p), r5a(p));
+            for (int t = 0; t < 6; ++t) q[t] = Zc(v, 0, 1, k - 3 + t);
+            for (int t = 0; t < 6; ++t) p[t] = A(w, 0, t - 2, k);
+            fn = upw(zfS(q, k, nz), l5a(p), r5a(p));
+            for (int t = 0; t < 6; ++t) q[t] = Zc(v, 0, 0, k - 3 + t);
+            for (int t = 0; t < 6; ++t) p[t] = A(w, 0, t - 3, k);
+            fs = upw(zfS(q, k, nz), l5a(p), r5a(p));
+            // flux_ww at centres k and k-1
+            for (int t = 0; t < 6; ++t) p[t] = Zw(0, 0, k - 2 + t);
+            const double ft = upw(zcS(p, k, nz), zcL(p, k, nz), zcR(p, k, nz));
+            for (int t = 0; t < 6; ++t) p[t] = Zw(0, 0, k - 3 + t);
+            const double fb = upw(zcS(p, k - 1, nz), zcL(p, k - 1, nz), zcR(p, k - 1, nz));
+            const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
+            const double vis = nu * ((((A(u, 1, 0, k) - A(u, 1, 0, k - 1)) * rdz + (A(w, 1, 0, k) - w0) * rdx)
+                                      - ((A(u, 0, 0, k) - A(u, 0, 0, k - 1)) * rdz + (w0 - A(w, -1, 0, k)) * rdx)) * rdx
+                                     + (((A(v, 0, 1, k) - A(v, 0, 1, k - 1)) * rdz + (A(w, 0, 1, k) - w0) * rdy)
+                                        - ((A(v, 0, 0, k) - A(v, 0, 0, k - 1)) * rdz + (w0 - A(w, 0, -1, k)) * rdy)) * rdy
+                                     + 2.0 * ((A(w, 0, 0, k + 1) - w0) - (w0 - A(w, 0, 0, k - 1))) * rdz * rdz);
+            G = vis - adv;
+        }
+    } else {
+        // ---- b at centre ----
+        double p[6];
+        double fe, fw, fn, fs, ft = 0.0, fb = 0.0;
+        for (int t = 0; t < 6; ++t) p[t] = A(b, t - 2, 0, k); fe = upw(A(u, 1, 0, k), l5a(p), r5a(p));
+        for (int t = 0; t < 6; ++t) p[t] = A(b, t - 3, 0, k); fw = upw(A(u, 0, 0, k), l5a(p), r5a(p));
+        for (int t = 0; t < 6; ++t) p[t] = A(b, 0, t - 2, k); fn = upw(A(v, 0, 1, k), l5a(p), r5a(p));
+        for (int t = 0; t < 6; ++t) p[t] = A(b, 0, t - 3, k); fs = upw(A(v, 0, 0, k), l5a(p), r5a(p));
+        if (k + 1 < nz) { for (int t = 0; t < 6; ++t) p[t] = Zc(b, 0, 0, k - 2 + t); ft = upw(A(w, 0, 0, k + 1), zfL(p, k + 1, nz), zfR(p, k + 1, nz)); }
+        if (k > 0) { for (int t = 0; t < 6; ++t) p[t] = Zc(b, 0, 0, k - 3 + t); fb = upw(A(w, 0, 0, k), zfL(p, k, nz), zfR(p, k, nz)); }
+        const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
+        const double b0 = A(b, 0, 0, k);
+        const double bup = (k + 1 < nz) ? A(b, 0, 0, k + 1) : ghost_hi(b0, g.min_b);
+        const double bdn = (k > 0) ? A(b, 0, 0, k - 1) : ghost_lo(b0, bottom_T(g, actT + (size_t)env * g.heaters * g.heaters, i, j));
+        const double dif = ka * (((A(b, 1, 0, k) - b0) - (b0 - A(b, -1, 0, k))) * rdx * rdx
+                                 + ((A(b, 0, 1, k) - b0) - (b0 - A(b, 0, -1, k))) * rdy * rdy
+                                 + ((bup - b0) - (b0 - bdn)) * rdz * rdz);
+        G = dif - adv;
+        old = b0;
+    }
+    // field offsets in the state layout: b,u,v,w
+    const size_t foff = (FIELD == 3) ? 0 : ((FIELD == 0) ? (size_t)g.nc : ((FIELD == 1) ? 2 * (size_t)g.nc : 3 * (size_t)g.nc));
+    const size_t o = (size_t)env * g.env_stride + foff + c0;
+    if (dbg) { dbg[((size_t)env * 4 + FIELD) * g.nc + c0] = G; return; }
+    const double gprev = gm[o];
+    nxt[o] = old + dt * (gam * G + zet * gprev);
+    gm[o] = G;
+    if (FIELD == 2 && k == nz - 1) nxt[(size_t)env * g.env_stride + 3 * (size_t)g.nc + c0 + nx * ny] = 0.0;   // top wall face
+}
+
+// ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------
+// data: [rows][n] complex (re,im interleaved), n = n1*n2, line stride `ls`, element stride `es`
+// (so the same routine does rows and columns).  out-of-place src -> dst.  sign=-1 forward, +1 inverse.
+__device__ inline void slab_dft(const double2 *src, double2 *dst, int lines, int n, int n1, int n2, int ls, int es,
+                                const double2 *tw, int sign, double2 *tmp)
+{
+    // stage 1: tmp[line][k1][n2'] = W_n^(n2' k1) * sum_{a<n1} src[line][n2*a + n2'] W_n1^(a k1)
+    for (int idx = threadIdx.x; idx < lines * n; idx += blockDim.x) {
+        const int line = idx / n, r = idx - line * n, k1 = r / n2, b2 = r - k1 * n2;
+        double sr = 0.0, si = 0.0;
+        for (int a = 0; a < n1; ++a) {
+            const double2 x = src[line * ls + (n2 * a + b2) * es];
+            const double2 t = tw[((a * k1) % n1) * n2];            // W_n1^(a k1) = W_n^(n2 a k1)
+            const double ti = sign < 0 ? -t.y : t.y;
+            sr += x.x * t.x - x.y * ti; si += x.x * ti + x.y * t.x;
+        }
+        const double2 t = tw[(b2 * k1) % n];
+        const double ti = sign < 0 ? -t.y : t.y;
+        tmp[line * n + k1 * n2 + b2] = make_double2(sr * t.x - si * ti, sr * ti + si * t.x);
+    }
+    __syncthreads();
+    // stage 2: dst[line][k1 + n1*k2] = sum_{b<n2} tmp[line][k1][b] W_n2^(b k2)
+    for (int idx = threadIdx.x; idx < lines * n; idx += blockDim.x) {
+        const int line = idx / n, r = idx - line * n, k2 = r / n1, k1 = r - k2 * n1;
+        double sr = 0.0, si = 0.0;
+        for (int b2 = 0; b2 < n2; ++b2) {
+            const double2 x = tmp[line * n + k1 * n2 + b2];
+            const double2 t = tw[((b2 * k2) % n2) * n1];
+            const double ti = sign < 0 ? -t.y : t.y;
+            sr += x.x * t.x - x.y * ti; si += x.x * ti + x.y * t.x;
+        }
+        dst[line * ls + (k1 + n1 * k2) * es] = make_double2(sr, si);
+    }
+    __syncthreads();
+}
+
+struct FftPlan { int nx1, nx2, ny1, ny2; };
+
+// forward: rhs slab (divergence of U*/dts) -> 2D spectrum.  One workgroup per (env, k).
+__global__ void k3_rhs_fft(Geo3 g, FftPlan pl, const double *st, double2 *spec, double dts)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny;
+    const int env = blockIdx.x / nz, k = blockIdx.x - env * nz;
+    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    const double *sb = st + (size_t)env * g.env_stride;
+    const double *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double rdt = 1.0 / dts;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) {
+        const int j = idx / nx, i = idx - j * nx;
+        const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1;
+        const size_t c = (size_t)k * pln + idx;
+        const double wt = (k + 1 < nz) ? w[c + pln] : 0.0;
+        const double wb = (k > 0) ? w[c] : 0.0;
+        const double d = (u[(size_t)k * pln + j * nx + ip] - u[c]) * g.rdx + (v[(size_t)k * pln + jp * nx + i] - v[c]) * g.rdy + (wt - wb) * g.rdz;
+        A[idx] = make_double2(d * rdt, 0.0);
+    }
+    __syncthreads();
+    slab_dft(A, A, ny, nx, pl.nx1, pl.nx2, nx, 1, twx, -1, T);     // along x (rows); in place is fine: stage 1 reads all before stage 2 writes
+    slab_dft(A, A, nx, ny, pl.ny1, pl.ny2, 1, nx, twy, -1, T);     // along y (columns)
+    double2 *o = spec + ((size_t)env * nz + k) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx];
+}
+
+// z sweep per (env, n, m): tab[k][n][m] = 1/pivot; mean mode pinned (its z-mean is removed on output)
+__global__ void k3_thomas(Geo3 g, double2 *spec, const double *tab, int B)
+{
+    const int pln = g.nx * g.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pln * B) return;
+    const int env = t / pln, mn = t - env * pln;
+    double2 *s = spec + (size_t)env * g.nz * pln + mn;
+    const double o = g.rdz * g.rdz;
+    double yr = 0.0, yi = 0.0;
+    for (int k = 0; k < g.nz; ++k) {
+        const double inv = tab[(size_t)k * pln + mn];
+        const double2 r = s[(size_t)k * pln];
+        yr = r.x * inv - (inv * o) * yr;
+        yi = r.y * inv - (inv * o) * yi;
+        s[(size_t)k * pln] = make_double2(yr, yi);
+    }
+    double xr = 0.0, xi = 0.0;
+    for (int k = g.nz - 1; k >= 0; --k) {
+        const double cp = tab[(size_t)k * pln + mn] * o;
+        const double2 y = s[(size_t)k * pln];
+        xr = y.x - cp * xr; xi = y.y - cp * xi;
+        s[(size_t)k * pln] = make_double2(xr, xi);
+    }
+}
+
+// inverse 2D FFT of one slab -> phi[env][k][j][i] (real part, normalised)
+__global__ void k3_ifft(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny;
+    const int env = blockIdx.x / nz, k = blockIdx.x - env * nz;
+    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    const double2 *in = spec + ((size_t)env * nz + k) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) A[idx] = in[idx];
+    __syncthreads();
+    slab_dft(A, A, nx, ny, pl.ny1, pl.ny2, 1, nx, twy, +1, T);
+    slab_dft(A, A, ny, nx, pl.nx1, pl.nx2, nx, 1, twx, +1, T);
+    const double sc = 1.0 / (double)pln;
+    double *o = phi + ((size_t)env * nz + k) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx].x * sc;
+}
+
+// pressure_correct_velocities!
+__global__ void k3_correct(Geo3 g, double *st, const double *phi, double dts, int B, const uint8_t *mask)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= g.nc * B) return;
+    const int env = cell / g.nc, c0 = cell - env * g.nc;
+    if (mask && !mask[env]) return;
+    const int nx = g.nx, ny = g.ny, pln = nx * ny;
+    const int k = c0 / pln, j = (c0 - k * pln) / nx, i = c0 - k * pln - j * nx;
+    const int im = (i == 0) ? nx - 1 : i - 1, jm = (j == 0) ? ny - 1 : j - 1;
+    double *sb = st + (size_t)env * g.env_stride;
+    const double *p = phi + (size_t)env * g.nc;
+    const double pc = p[c0];
+    sb[g.nc + c0] -= (pc - p[(size_t)k * pln + j * nx + im]) * g.rdx * dts;
+    sb[2 * (size_t)g.nc + c0] -= (pc - p[(size_t)k * pln + jm * nx + i]) * g.rdy * dts;
+    if (k > 0) sb[3 * (size_t)g.nc + c0] -= (pc - p[c0 - pln]) * g.rdz * dts;
+}
+
+// copy b (unchanged by a projection-only pass) between state buffers
+__global__ void k3_copy(double *dst, const double *src, size_t n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+
+// random IC: initialize_model, rbc_sim3D.jl:169-179 (fields 0:u 1:v 2:w 3:b of the counter RNG)
+__global__ void k3_random(Geo3 g, double *st, const uint64_t *seeds, const uint8_t *mask, int B)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= g.nw * B) return;
+    const int env = cell / g.nw, c0 = cell - env * g.nw;
+    if (mask && !mask[env]) return;
+    const int pln = g.nx * g.ny, k = c0 / pln;
+    double *sb = st + (size_t)env * g.env_stride;
+    const uint64_t seed = seeds[env];
+    sb[3 * (size_t)g.nc + c0] = (k == 0 || k == g.nz) ? 0.0 : g.kick * rbc::normal_deviate(seed, 2, (uint32_t)c0);
+    if (k < g.nz) {
+        sb[g.nc + c0] = g.kick * rbc::normal_deviate(seed, 0, (uint32_t)c0);
+        sb[2 * (size_t)g.nc + c0] = g.kick * rbc::normal_deviate(seed, 1, (uint32_t)c0);
+        const double z = (k + 0.5) * g.dz;
+        const double val = g.min_b + (g.lz - z) * g.delta_b / 2 + g.kick * rbc::normal_deviate(seed, 3, (uint32_t)c0);
+        sb[c0] = fmin(fmax(val, g.min_b), g.min_b + g.delta_b);
+    }
+}
+
+// outputs: float32 state (b,u,v,w), Nusselt (rbc_sim3D_api.jl:134-159), NaN flag.  One workgroup per env.
+__global__ void k3_output(Geo3 g, const double *st, const double *nu_kappa, float *state32, double *nusselt, int *flags, const uint8_t *mask)
+{
+    __shared__ double red[256];
+    __shared__ int bad;
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const double *sb = st + (size_t)env * g.env_stride;
+    const int pln = g.nx * g.ny;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    double acc = 0.0;
+    int nan = 0;
+    float *o = state32 + (size_t)env * 4 * g.nc;
+    for (int c0 = threadIdx.x; c0 < g.nc; c0 += blockDim.x) {
+        const int k = c0 / pln;
+        const double b = sb[c0], u = sb[g.nc + c0], v = sb[2 * (size_t)g.nc + c0], w = sb[3 * (size_t)g.nc + c0];
+        o[c0] = (float)b; o[g.nc + c0] = (float)u; o[2 * (size_t)g.nc + c0] = (float)v; o[3 * (size_t)g.nc + c0] = (float)w;
+        const double zc = (k + 0.5) / g.nz, tc = (1.0 - zc) * g.delta_b + g.min_b;
+        acc += (b - tc) * w;
+        nan |= (isnan(b) || isnan(u) || isnan(v) || isnan(w)) ? 1 : 0;
+    }
+    red[threadIdx.x] = acc;
+    if (nan) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int t = 0; t < (int)blockDim.x; ++t) s += red[t];
+        nusselt[env] = 1.0 + (s / (double)g.nc) / nu_kappa[2 * env + 1];
+        flags[env] = bad;
+    }
+}
+
+}  // namespace rbc3

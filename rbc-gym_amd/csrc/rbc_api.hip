@@ -34,8 +34,11 @@ int fail(int code, const std::string &msg)
 
 }  // namespace
 
+struct rbc3_state;
+
 struct rbc_handle {
     rbc_config cfg;
+    rbc3_state *s3 = nullptr;          // non-null for dim == 3 (rbc3d_host.hpp)
     int B = 0, nx = 0, nz = 0;
     size_t ncell = 0, env_stride = 0, obs_sz = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -53,11 +56,13 @@ struct rbc_handle {
     size_t ev_used = 0;               // pairs recorded since the last rbc_profile_read
     bool profiling = false;
     int nsub = 0;
-    double dt_last = 0.0;
+    double dt_last = 0.0, dt_solver_eff = 0.0;
     void (*kernel)(const rbc::Params2D) = nullptr;
     size_t lds_bytes = 0;
     int threads = 0;
 };
+
+#include "rbc3d_host.hpp"
 
 namespace {
 
@@ -190,29 +195,35 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     if (!cfg || !out) return fail(RBC_ERR_INVALID, "null argument");
     *out = nullptr;
     if (cfg->abi_version != RBC_ABI_VERSION) return fail(RBC_ERR_INVALID, "rbc_config.abi_version mismatch");
-    if (cfg->dim != 2) return fail(RBC_ERR_INVALID, "only dim=2 is implemented in this build");
+    if (cfg->dim != 2 && cfg->dim != 3) return fail(RBC_ERR_INVALID, "dim must be 2 or 3");
     if (cfg->batch < 1) return fail(RBC_ERR_INVALID, "batch must be >= 1");
     if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
     if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
         return fail(RBC_ERR_INVALID, "ra, pr, dt_solver, dt_control must be positive");
-    if (cfg->obs_nx < 1 || cfg->obs_nz < 2 || cfg->nx % cfg->obs_nx || cfg->nz % cfg->obs_nz)
+    if (cfg->dim == 2 && (cfg->obs_nx < 1 || cfg->obs_nz < 2 || cfg->nx % cfg->obs_nx || cfg->nz % cfg->obs_nz))
         return fail(RBC_ERR_INVALID, "sensor grid must divide the state grid (and have >= 2 rows)");
+    if (cfg->dim == 3 && (cfg->nx < 8 || cfg->ny < 8 || cfg->nz < 8 || !(cfg->ly > 0)))
+        return fail(RBC_ERR_INVALID, "3D grid must be at least 8 cells in every direction");
 
     auto *h = new rbc_handle();
     h->cfg = *cfg;
     h->B = cfg->batch; h->nx = cfg->nx; h->nz = cfg->nz;
-    if (cfg->nx == 96 && cfg->nz == 64) bind_kernel<96, 64>(h);
+    if (cfg->dim == 3) { /* streaming kernels, any grid whose horizontal slab fits the LDS FFT */ }
+    else if (cfg->nx == 96 && cfg->nz == 64) bind_kernel<96, 64>(h);
     else if (cfg->nx == 96 && cfg->nz == 48) bind_kernel<96, 48>(h);
     else if (cfg->nx == 96 && cfg->nz == 32) bind_kernel<96, 32>(h);
     else {
         delete h;
         return fail(RBC_ERR_INVALID, "unsupported grid: the LDS-resident 2D kernel is built for nx=96, nz in {32,48,64}");
     }
-    h->ncell = (size_t)h->nx * h->nz;
+    h->ncell = (size_t)h->nx * h->nz * (cfg->dim == 3 ? cfg->ny : 1);
     h->env_stride = (size_t)(3 * h->nz + 1) * h->nx;
     h->obs_sz = (size_t)cfg->obs_nx * cfg->obs_nz;
     {
-        const double T = cfg->dt_control, dt = cfg->dt_solver;
+        // 3D: the reference runs in free-fall units, solver/control steps are scaled by t_ff = lz^2 (rbc_sim3D_api.jl:43,65)
+        const double tff = (cfg->dim == 3) ? cfg->lz * cfg->lz : 1.0;
+        const double T = cfg->dt_control * tff, dt = cfg->dt_solver * tff;
+        h->dt_solver_eff = dt;
         int nfull = (int)std::floor(T / dt + 1e-9);
         double rem = T - nfull * dt;
         if (rem > 1e-9 * dt) { h->nsub = nfull + 1; h->dt_last = rem; }
@@ -237,18 +248,33 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     const size_t B = h->B;
-    CREATE_TRY(hipMalloc(&h->d_fields, B * h->env_stride * sizeof(double)));
-    CREATE_TRY(hipMemset(h->d_fields, 0, B * h->env_stride * sizeof(double)));
+    const size_t nact = (cfg->dim == 3) ? (size_t)cfg->heaters * cfg->heaters : (size_t)cfg->heaters;
     CREATE_TRY(hipMalloc(&h->d_ra, B * 2 * sizeof(double)));   // (nu, kappa) per env
-    CREATE_TRY(hipMalloc(&h->d_actions, B * cfg->heaters * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->d_actions, B * nact * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->d_mask, B));
     CREATE_TRY(hipMalloc(&h->d_seeds, B * sizeof(uint64_t)));
-    CREATE_TRY(hipMalloc(&h->d_obs, B * 5 * h->obs_sz * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->d_state, B * 5 * h->ncell * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->d_nu, B * 2 * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_park, B * 2 * rbc::CZ * (size_t)h->threads * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_flags, B * sizeof(int)));
     CREATE_TRY(hipMemset(h->d_flags, 0, B * sizeof(int)));
+    {
+        std::vector<double> nk(2 * B);
+        for (size_t e = 0; e < B; ++e) { nk[2 * e] = std::sqrt(cfg->pr / cfg->ra); nk[2 * e + 1] = 1.0 / std::sqrt(cfg->pr * cfg->ra); }
+        CREATE_TRY(hipMemcpy(h->d_ra, nk.data(), nk.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (cfg->dim == 3) {
+        CREATE_TRY(hipMalloc(&h->d_state, B * 4 * h->ncell * sizeof(float)));
+        if (int rc = create3d(h)) { rbc_destroy(h); return rc; }
+        h->t.assign(B, 0.0);
+        h->step.assign(B, 1);
+        h->inited.assign(B, 0);
+        *out = h;
+        return RBC_OK;
+    }
+    CREATE_TRY(hipMalloc(&h->d_fields, B * h->env_stride * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_fields, 0, B * h->env_stride * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_obs, B * 5 * h->obs_sz * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->d_state, B * 5 * h->ncell * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->d_park, B * 2 * rbc::CZ * (size_t)h->threads * sizeof(double)));
 #if RBC_STAMPS
     CREATE_TRY(hipMalloc(&h->d_stamps, B * 64 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_stamps, 0, B * 64 * sizeof(unsigned long long)));
@@ -257,9 +283,6 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
         std::vector<double> tab = tri_table(h->nx, h->nz, cfg->lx, cfg->lz);
         CREATE_TRY(hipMalloc(&h->d_tri, tab.size() * sizeof(double)));
         CREATE_TRY(hipMemcpy(h->d_tri, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-        std::vector<double> nk(2 * B);
-        for (size_t e = 0; e < B; ++e) { nk[2 * e] = std::sqrt(cfg->pr / cfg->ra); nk[2 * e + 1] = 1.0 / std::sqrt(cfg->pr * cfg->ra); }
-        CREATE_TRY(hipMemcpy(h->d_ra, nk.data(), nk.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes));
@@ -276,6 +299,7 @@ int rbc_destroy(rbc_handle *h)
     if (!h) return RBC_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    destroy3d(h);
     void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_park, h->d_actions, h->d_obs, h->d_state,
                     h->d_mask, h->d_seeds, h->d_flags, h->d_stamps};
     for (void *b : bufs)
@@ -349,6 +373,14 @@ int rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds)
     if (int rc = upload_mask(h, mask, m)) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->s3) {
+        rbc3_state *s = h->s3;
+        hipLaunchKernelGGL(rbc3::k3_random, grid_for((size_t)h->B * s->g.nw, 256), dim3(256), 0, h->stream, s->g, s->st[s->cur],
+                           h->d_seeds, h->d_mask, h->B);
+        if (int rc = finish_reset3d(h)) return rc;
+        mark_reset(h, m);
+        return RBC_OK;
+    }
     rbc::Params2D p = base_params(h);
     p.mode = rbc::MODE_RANDOM;
     p.mask = h->d_mask;
@@ -358,9 +390,35 @@ int rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds)
     return RBC_OK;
 }
 
+int rbc_reset_from_arrays3(rbc_handle *h, const uint8_t *mask, const double *b, const double *u, const double *v, const double *w)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!h->s3) return fail(RBC_ERR_INVALID, "rbc_reset_from_arrays3 needs a dim=3 handle");
+    if (!b || !u || !v || !w) return fail(RBC_ERR_INVALID, "null field array");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<uint8_t> m;
+    if (int rc = upload_mask(h, mask, m)) return rc;
+    rbc3_state *s = h->s3;
+    const size_t nc = s->g.nc, nw = s->g.nw;
+    h->stage.resize(s->g.env_stride);
+    for (int e = 0; e < h->B; ++e) {
+        if (!m[e]) continue;
+        std::memcpy(h->stage.data(), b + (size_t)e * nc, nc * sizeof(double));
+        std::memcpy(h->stage.data() + nc, u + (size_t)e * nc, nc * sizeof(double));
+        std::memcpy(h->stage.data() + 2 * nc, v + (size_t)e * nc, nc * sizeof(double));
+        std::memcpy(h->stage.data() + 3 * nc, w + (size_t)e * nw, nw * sizeof(double));
+        HIP_TRY(hipMemcpy(s->st[s->cur] + (size_t)e * s->g.env_stride, h->stage.data(), s->g.env_stride * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+    if (int rc = finish_reset3d(h)) return rc;
+    mark_reset(h, m);
+    return RBC_OK;
+}
+
 int rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask, const double *b, const double *u, const double *w)
 {
     if (int rc = check_handle(h)) return rc;
+    if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_reset_from_arrays3 (b,u,v,w)");
     if (!b || !u || !w) return fail(RBC_ERR_INVALID, "null field array");
     HIP_TRY(hipSetDevice(h->cfg.device));
     std::vector<uint8_t> m;
@@ -387,7 +445,7 @@ int rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask, const double *b, c
 static void advance_clocks(rbc_handle *h)
 {
     for (int e = 0; e < h->B; ++e) {
-        h->t[e] += h->cfg.dt_control;   // api:87
+        h->t[e] += h->cfg.dt_control * (h->s3 ? h->cfg.lz * h->cfg.lz : 1.0);   // api:87 (3D: rbc_sim3D_api.jl:89)
         h->step[e] += 1;                // api:88
     }
 }
@@ -398,6 +456,11 @@ int rbc_step_dev(rbc_handle *h, const float *actions_dev)
     if (int rc = all_initialized(h)) return rc;
     if (!actions_dev) return fail(RBC_ERR_INVALID, "null actions");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->s3) {
+        if (int rc = step3d(h, actions_dev, h->nsub, h->dt_solver_eff, h->dt_last, true)) return rc;
+        advance_clocks(h);
+        return RBC_OK;
+    }
     rbc::Params2D p = base_params(h);
     p.actions = actions_dev;
     if (int rc = launch(h, p, true)) return rc;
@@ -411,7 +474,8 @@ int rbc_step(rbc_handle *h, const float *actions)
     if (int rc = all_initialized(h)) return rc;
     if (!actions) return fail(RBC_ERR_INVALID, "null actions");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    HIP_TRY(hipMemcpyAsync(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice,
+    const size_t nact = h->s3 ? (size_t)h->cfg.heaters * h->cfg.heaters : (size_t)h->cfg.heaters;
+    HIP_TRY(hipMemcpyAsync(h->d_actions, actions, (size_t)h->B * nact * sizeof(float), hipMemcpyHostToDevice,
                            h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // `actions` may be pageable: do not return before it is consumed
     if (int rc = rbc_step_dev(h, h->d_actions)) return rc;
@@ -425,11 +489,12 @@ int rbc_step(rbc_handle *h, const float *actions)
 
 static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t chan, int nch)
 {
+    const int total = h->s3 ? 4 : 5;       // 3D: b,u,v,w (rbc_sim3D_api.jl:106-121); 2D: b,u,w,pHY',pNHS
     if (!out) return fail(RBC_ERR_INVALID, "null output");
-    if (nch < 1 || nch > 5) return fail(RBC_ERR_INVALID, "nch must be in 1..5");
+    if (nch < 1 || nch > total) return fail(RBC_ERR_INVALID, "nch out of range");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy2D(out, (size_t)nch * chan * sizeof(float), dev, 5 * chan * sizeof(float),
+    HIP_TRY(hipMemcpy2D(out, (size_t)nch * chan * sizeof(float), dev, total * chan * sizeof(float),
                         (size_t)nch * chan * sizeof(float), h->B, hipMemcpyDeviceToHost));
     return RBC_OK;
 }
@@ -438,6 +503,7 @@ int rbc_get_obs(rbc_handle *h, float *out, int nch)
 {
     if (int rc = check_handle(h)) return rc;
     if (int rc = all_initialized(h)) return rc;
+    if (h->s3) return copy_channels(h, out, h->d_state, h->ncell, nch);     // 3D: the observation IS the state (rbc3D.py:229-232)
     return copy_channels(h, out, h->d_obs, h->obs_sz, nch);
 }
 
@@ -445,13 +511,30 @@ int rbc_get_state(rbc_handle *h, float *out, int nch)
 {
     if (int rc = check_handle(h)) return rc;
     if (int rc = all_initialized(h)) return rc;
-    if (!h->cfg.write_state) return fail(RBC_ERR_INVALID, "handle was created with write_state=0");
+    if (!h->s3 && !h->cfg.write_state) return fail(RBC_ERR_INVALID, "handle was created with write_state=0");
     return copy_channels(h, out, h->d_state, h->ncell, nch);
+}
+
+int rbc_get_fields3(rbc_handle *h, double *b, double *u, double *v, double *w)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!h->s3) return fail(RBC_ERR_INVALID, "rbc_get_fields3 needs a dim=3 handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    rbc3_state *s = h->s3;
+    const size_t nc = s->g.nc, nw = s->g.nw, pitch = s->g.env_stride * sizeof(double);
+    const double *base = s->st[s->cur];
+    if (b) HIP_TRY(hipMemcpy2D(b, nc * sizeof(double), base, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    if (u) HIP_TRY(hipMemcpy2D(u, nc * sizeof(double), base + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    if (v) HIP_TRY(hipMemcpy2D(v, nc * sizeof(double), base + 2 * nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    if (w) HIP_TRY(hipMemcpy2D(w, nw * sizeof(double), base + 3 * nc, pitch, nw * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    return RBC_OK;
 }
 
 int rbc_get_fields(rbc_handle *h, double *b, double *u, double *w)
 {
     if (int rc = check_handle(h)) return rc;
+    if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_get_fields3");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t nc = h->ncell, nw = nc + h->nx, pitch = h->env_stride * sizeof(double);
@@ -470,6 +553,11 @@ int rbc_get_nusselt(rbc_handle *h, double *nu_state, double *nu_obs)
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_nu, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int e = 0; e < h->B; ++e) {
+        if (h->s3) {                         // 3D has one Nusselt number (rbc_sim3D_api.jl:134): d_nu is [B]
+            if (nu_state) nu_state[e] = tmp[e];
+            if (nu_obs) nu_obs[e] = tmp[e];
+            continue;
+        }
         if (nu_state) nu_state[e] = tmp[2 * e];
         if (nu_obs) nu_obs[e] = tmp[2 * e + 1];
     }
@@ -500,7 +588,7 @@ void *rbc_dev_obs(rbc_handle *h) { return h ? h->d_obs : nullptr; }
 void *rbc_dev_state(rbc_handle *h) { return h ? h->d_state : nullptr; }
 void *rbc_dev_nusselt(rbc_handle *h) { return h ? h->d_nu : nullptr; }
 void *rbc_dev_flags(rbc_handle *h) { return h ? h->d_flags : nullptr; }
-void *rbc_dev_fields(rbc_handle *h) { return h ? h->d_fields : nullptr; }
+void *rbc_dev_fields(rbc_handle *h) { return h ? (h->s3 ? (void *)h->s3->st[h->s3->cur] : (void *)h->d_fields) : nullptr; }
 
 int rbc_set_profiling(rbc_handle *h, int max_launches)
 {
@@ -536,13 +624,43 @@ int rbc_profile_read(rbc_handle *h, double *ms, int capacity)
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h)
 {
     if (!h) return 0.0;
-    // B_sub = 10 * F * C * s (F=3 prognostic fields, C cells, s=8 bytes) per RK3 substep
-    return (double)h->nsub * 10.0 * 3.0 * (double)h->ncell * 8.0;
+    // B_sub = 10 * F * C * s (F prognostic fields: 3 in 2D, 4 in 3D; C cells; s=8 bytes) per RK3 substep
+    return (double)h->nsub * 10.0 * (h->s3 ? 4.0 : 3.0) * (double)h->ncell * 8.0;
+}
+
+int rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, double *gv, double *gw, double *gb)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (!h->s3) return fail(RBC_ERR_INVALID, "needs a dim=3 handle");
+    if (!actions || !gu || !gv || !gw || !gb) return fail(RBC_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    rbc3_state *s = h->s3;
+    const rbc3::Geo3 &g = s->g;
+    const int B = h->B;
+    const size_t nc = g.nc;
+    if (!s->dbg) HIP_TRY(hipMalloc(&s->dbg, (size_t)B * 4 * nc * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)B * g.heaters * g.heaters * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(B), dim3(64), 0, h->stream, g, h->d_actions, s->actT, 0);
+    double *cur = s->st[s->cur];
+    hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
+    const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
+    hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+    hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+    hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+    hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t pitch = 4 * nc * sizeof(double);
+    double *outs[4] = {gu, gv, gw, gb};
+    for (int q = 0; q < 4; ++q)
+        HIP_TRY(hipMemcpy2D(outs[q], nc * sizeof(double), s->dbg + q * nc, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
+    return RBC_OK;
 }
 
 int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw)
 {
     if (int rc = check_handle(h)) return rc;
+    if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_debug_tendencies3");
     if (!actions || !gb || !gu || !gw) return fail(RBC_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t nc = h->ncell;
@@ -577,6 +695,12 @@ int rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt)
     if (int rc = check_handle(h)) return rc;
     if (!actions || nsub < 1 || !(dt > 0)) return fail(RBC_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->s3) {
+        HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice));
+        if (int rc = step3d(h, h->d_actions, nsub, dt, dt, false)) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return RBC_OK;
+    }
     HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice));
     rbc::Params2D p = base_params(h);
     p.actions = h->d_actions;

@@ -66,6 +66,9 @@ SYMBOLS = {
     "rbc_debug_tendencies": (C.c_int, [_vp, _fp, _dp, _dp, _dp]),
     "rbc_debug_substeps": (C.c_int, [_vp, _fp, C.c_int, C.c_double]),
     "rbc_debug_stamps": (C.c_int, [_vp, _u64p]),
+    "rbc_reset_from_arrays3": (C.c_int, [_vp, _u8p, _dp, _dp, _dp, _dp]),
+    "rbc_get_fields3": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "rbc_debug_tendencies3": (C.c_int, [_vp, _fp, _dp, _dp, _dp, _dp]),
 }
 
 _lib = None
@@ -248,3 +251,131 @@ class NativeSim:
         L = self.lib
         return dict(obs=L.rbc_dev_obs(self.h), state=L.rbc_dev_state(self.h), nusselt=L.rbc_dev_nusselt(self.h),
                     flags=L.rbc_dev_flags(self.h), fields=L.rbc_dev_fields(self.h))
+
+
+class NativeSim3D:
+    """A batch of B 3D envs on one GPU (rbc_sim3D_api.jl semantics; array shapes (nz, ny, nx))."""
+
+    def __init__(self, batch=1, device=0, shape=(16, 32, 32), domain=(2.0, 4 * np.pi, 4 * np.pi), ra=2500.0, pr=0.7,
+                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01):
+        self.lib = load_library()
+        cfg = default_config()
+        nz, ny, nx = shape
+        lz, ly, lx = domain
+        cfg.dim, cfg.nx, cfg.ny, cfg.nz = 3, int(nx), int(ny), int(nz)
+        cfg.lx, cfg.ly, cfg.lz = float(lx), float(ly), float(lz)
+        cfg.ra, cfg.pr = float(ra), float(pr)
+        cfg.min_b, cfg.delta_b = float(t_diff[0]), float(t_diff[1] - t_diff[0])
+        cfg.heaters, cfg.heater_limit = int(heaters), float(heater_limit)
+        cfg.dt_control, cfg.dt_solver = float(dt_control), float(dt_solver)
+        cfg.obs_nx, cfg.obs_nz = int(nx), int(nz)
+        cfg.batch, cfg.device = int(batch), int(device)
+        self.cfg = cfg
+        self.h = _vp()
+        rc = self.lib.rbc_create(C.byref(cfg), C.byref(self.h))
+        if rc != RBC_OK:
+            raise RbcError(rc, self.lib.rbc_last_error().decode())
+        self.B, self.nx, self.ny, self.nz, self.heaters = cfg.batch, nx, ny, nz, heaters
+
+    def _check(self, rc):
+        if rc != RBC_OK:
+            raise RbcError(rc, self.lib.rbc_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rbc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _mask(self, mask):
+        if mask is None:
+            return None
+        self._m = np.ascontiguousarray(mask, dtype=np.uint8)
+        return _ptr(self._m, _u8p)
+
+    def reset(self, seeds, mask=None):
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.B,)))
+        self._check(self.lib.rbc_reset(self.h, self._mask(mask), _ptr(s, _u64p)))
+
+    def reset_from_arrays(self, b, u, v, w, mask=None):
+        a = [np.ascontiguousarray(x, np.float64) for x in (b, u, v, w)]
+        assert a[0].shape == (self.B, self.nz, self.ny, self.nx) and a[3].shape == (self.B, self.nz + 1, self.ny, self.nx)
+        self._check(self.lib.rbc_reset_from_arrays3(self.h, self._mask(mask), *[_ptr(x, _dp) for x in a]))
+
+    def set_rayleigh(self, ra):
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(ra, np.float64), (self.B,)))
+        self._check(self.lib.rbc_set_rayleigh(self.h, _ptr(r, _dp)))
+
+    def _actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.B, self.heaters, self.heaters):
+            raise ValueError(f"actions must have shape {(self.B, self.heaters, self.heaters)}, got {a.shape}")
+        return a
+
+    def step(self, actions):
+        a = self._actions(actions)
+        rc = self.lib.rbc_step(self.h, _ptr(a, _fp))
+        if rc == RBC_ERR_NAN:
+            return False
+        self._check(rc)
+        return True
+
+    def step_dev(self, actions_dev_ptr):
+        self._check(self.lib.rbc_step_dev(self.h, _vp(actions_dev_ptr)))
+
+    def get_state(self):
+        o = np.empty((self.B, 4, self.nz, self.ny, self.nx), np.float32)
+        self._check(self.lib.rbc_get_state(self.h, _ptr(o, _fp), 4))
+        return o
+
+    get_obs = get_state          # rbc3D.py:229-232: the observation is the full state
+
+    def get_fields(self):
+        s = (self.B, self.nz, self.ny, self.nx)
+        b, u, v, w = np.empty(s), np.empty(s), np.empty(s), np.empty((self.B, self.nz + 1, self.ny, self.nx))
+        self._check(self.lib.rbc_get_fields3(self.h, *[_ptr(x, _dp) for x in (b, u, v, w)]))
+        return b, u, v, w
+
+    def get_nusselt(self):
+        a = np.empty(self.B)
+        self._check(self.lib.rbc_get_nusselt(self.h, _ptr(a, _dp), None))
+        return a
+
+    def get_info(self):
+        t = np.empty(self.B); s = np.empty(self.B, np.int64)
+        self._check(self.lib.rbc_get_info(self.h, _ptr(t, _dp), _ptr(s, _i64p)))
+        return t, s
+
+    def get_flags(self):
+        f = np.empty(self.B, np.int32)
+        self._check(self.lib.rbc_get_flags(self.h, _ptr(f, _i32p)))
+        return f
+
+    def synchronize(self):
+        self._check(self.lib.rbc_synchronize(self.h))
+
+    def set_profiling(self, n):
+        self._check(self.lib.rbc_set_profiling(self.h, int(n)))
+
+    def profile_read(self, capacity=4096):
+        ms = np.empty(capacity)
+        k = self.lib.rbc_profile_read(self.h, _ptr(ms, _dp), capacity)
+        return ms[:max(k, 0)].copy()
+
+    def algorithmic_bytes_per_env_step(self):
+        return self.lib.rbc_algorithmic_bytes_per_env_step(self.h)
+
+    def debug_tendencies(self, actions):
+        a = self._actions(actions)
+        g = [np.empty((self.B, self.nz, self.ny, self.nx)) for _ in range(4)]
+        self._check(self.lib.rbc_debug_tendencies3(self.h, _ptr(a, _fp), *[_ptr(x, _dp) for x in g]))
+        return dict(u=g[0], v=g[1], w=g[2], b=g[3])
+
+    def debug_substeps(self, actions, nsub, dt):
+        a = self._actions(actions)
+        self._check(self.lib.rbc_debug_substeps(self.h, _ptr(a, _fp), int(nsub), float(dt)))

@@ -1,0 +1,118 @@
+"""GPU parity, 3D: the streaming HIP path (through the C ABI) against the 3D CPU oracle on
+identical inputs (fp64; tolerances per test).  The oracle itself is anchored on the 2D one
+(tests/test_oracle3d.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (16, 24, 32)          # (nz, ny, nx): non-square slab exercises both FFT factorisations (4x6, 4x8)
+DOMAIN = (2.0, 3 * np.pi, 4 * np.pi)
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from rbc_gym import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def o3():
+    import oracle_py
+    oracle_py.build_oracle()
+    return oracle_py
+
+
+def _developed_state(o3, seed, ra=5000.0):
+    """a few oracle substeps from a kicked state so that every term of the operator is active"""
+    o = o3.Oracle3D(ra=ra, shape=SHAPE, domain=DOMAIN, kick=0.2)
+    o.reset_random(seed)
+    act = np.random.default_rng(seed).uniform(-1, 1, (8, 8)).astype(np.float32)
+    o.set_action(act); o.update_state()
+    for _ in range(3):
+        o.substep(0.04)
+    return o.fields()
+
+
+def test_random_reset_and_projection(native, o3):
+    seeds = np.array([3, 77], dtype=np.uint64)
+    sim = native.NativeSim3D(batch=2, shape=SHAPE, domain=DOMAIN, ra=5000.0)
+    sim.reset(seeds)
+    b, u, v, w = sim.get_fields()
+    nu = sim.get_nusselt()
+    for e in range(2):
+        o = o3.Oracle3D(ra=5000.0, shape=SHAPE, domain=DOMAIN)
+        o.reset_random(int(seeds[e]))
+        ob, ou, ov, ow = o.fields()
+        assert np.abs(b[e] - ob).max() < 1e-14
+        for x, y in ((u[e], ou), (v[e], ov), (w[e], ow)):
+            assert np.abs(x - y).max() < 1e-13
+        dx, dy, dz = DOMAIN[2] / SHAPE[2], DOMAIN[1] / SHAPE[1], DOMAIN[0] / SHAPE[0]
+        div = (np.roll(u[e], -1, 2) - u[e]) / dx + (np.roll(v[e], -1, 1) - v[e]) / dy + (w[e][1:] - w[e][:-1]) / dz
+        assert np.abs(div).max() < 1e-13
+        assert abs(nu[e] - o.nusselt()) < 1e-10
+    t, s = sim.get_info()
+    assert np.all(t == 0) and np.all(s == 1)
+
+
+def test_tendencies_match_oracle(native, o3):
+    ics = [_developed_state(o3, 11), _developed_state(o3, 12, ra=20000.0)]
+    ras = [5000.0, 20000.0]
+    sim = native.NativeSim3D(batch=2, shape=SHAPE, domain=DOMAIN)
+    sim.set_rayleigh(ras)
+    sim.reset_from_arrays(*[np.stack([ic[q] for ic in ics]) for q in range(4)])
+    act = np.random.default_rng(5).uniform(-1, 1, (2, 8, 8)).astype(np.float32)
+    g = sim.debug_tendencies(act)
+    for e in range(2):
+        o = o3.Oracle3D(ra=ras[e], shape=SHAPE, domain=DOMAIN)
+        o.reset_from_arrays(*ics[e])
+        o.set_action(act[e]); o.update_state()
+        go = o.tendencies()
+        for f in "uvwb":
+            assert np.abs(g[f][e] - go[f]).max() < 1e-11 * max(np.abs(go[f]).max(), 1.0), f
+
+
+def test_env_step_matches_oracle(native, o3):
+    ic = _developed_state(o3, 21)
+    sim = native.NativeSim3D(batch=1, shape=SHAPE, domain=DOMAIN, ra=5000.0, dt_control=0.055, dt_solver=0.01)   # 5 x 0.04 + 0.02
+    sim.reset_from_arrays(*[x[None] for x in ic])
+    o = o3.Oracle3D(ra=5000.0, shape=SHAPE, domain=DOMAIN, dt_control=0.055, dt_solver=0.01)
+    o.reset_from_arrays(*ic)
+    for n in range(2):
+        act = np.random.default_rng(30 + n).uniform(-1, 1, (1, 8, 8)).astype(np.float32)
+        assert sim.step(act) and o.step(act[0])
+        for x, y in zip(sim.get_fields(), o.fields()):
+            assert rel_l2(x[0], y) < 1e-11
+        assert abs(sim.get_nusselt()[0] - o.nusselt()) < 1e-9 * abs(o.nusselt())
+        assert np.allclose(sim.get_state()[0], o.state(), rtol=1e-5, atol=1e-6)
+    t, s = sim.get_info()
+    assert abs(t[0] - 2 * 0.055 * 4) < 1e-12 and s[0] == 3            # rbc_sim3D_api.jl:89: time += dt * t_ff
+
+
+def test_masked_reset_batch_independence_and_nan(native, o3):
+    ic = _developed_state(o3, 41)
+    B = 3
+    arrs = [np.stack([x] * B) for x in ic]
+    act = np.random.default_rng(2).uniform(-1, 1, (B, 8, 8)).astype(np.float32)
+    act[2] = act[0]
+    sim = native.NativeSim3D(batch=B, shape=SHAPE, domain=DOMAIN, ra=5000.0, dt_control=0.02)
+    with pytest.raises(native.RbcError):
+        sim.step(act)
+    sim.reset_from_arrays(*arrs)
+    assert sim.step(act)
+    f = sim.get_fields()
+    for q in range(4):
+        assert np.array_equal(f[q][0], f[q][2]) and not np.array_equal(f[q][0], f[q][1])
+    bad = [a.copy() for a in arrs]
+    bad[0][1, 3, 3, 3] = np.nan
+    sim.reset_from_arrays(*bad, mask=[0, 1, 0])
+    g = sim.get_fields()
+    assert np.array_equal(g[1][0], f[1][0]) and np.array_equal(g[1][2], f[1][2])      # unmasked envs untouched
+    t, s = sim.get_info()
+    assert list(s) == [2, 1, 2]
+    assert not sim.step(act)
+    assert list(sim.get_flags()) == [0, 1, 0]
