@@ -211,21 +211,30 @@ def read_checkpoint(path):
         raise FileNotFoundError(path)
     if path.endswith(".npz"):
         z = np.load(path)
-        b, u, w = (np.ascontiguousarray(z[k], np.float64) for k in ("b", "u", "w"))
-        return dict(b=b, u=u, w=w, num_episodes=int(b.shape[0]), start_seed=int(z["start_seed"]) if "start_seed" in z.files else -1)
+        out = {k: np.ascontiguousarray(z[k], np.float64) for k in ("b", "u", "v", "w") if k in z.files}
+        out["num_episodes"] = int(out["b"].shape[0])
+        out["start_seed"] = int(z["start_seed"]) if "start_seed" in z.files else -1
+        return out
     h = _MiniHDF5(path)
     out = {}
-    for k in ("b", "u", "w"):
-        a = h.read(k)                       # (Nz[+1], 1, Nx, E) as stored by the reference's writer
-        if a.ndim != 4 or a.shape[1] != 1:
-            raise ValueError(f"{path}: dataset {k} has unexpected shape {a.shape} (expected a 2D checkpoint)")
-        out[k] = np.ascontiguousarray(np.moveaxis(a[:, 0], -1, 0), dtype=np.float64)
+    names = ("b", "u", "v", "w") if "v" in h.datasets else ("b", "u", "w")
+    for k in names:
+        a = h.read(k)                       # (Nz[+1], Ny, Nx, E) as stored by the reference's writer (Ny = 1 in 2D)
+        if a.ndim != 4:
+            raise ValueError(f"{path}: dataset {k} has unexpected shape {a.shape}")
+        a = np.moveaxis(a, -1, 0)           # (E, Nz[+1], Ny, Nx)
+        if "v" not in h.datasets:
+            if a.shape[2] != 1:
+                raise ValueError(f"{path}: dataset {k} has unexpected shape {a.shape} (expected a 2D checkpoint)")
+            a = a[:, :, 0]
+        out[k] = np.ascontiguousarray(a, dtype=np.float64)
     out["num_episodes"] = int(h.attrs.get("num_episodes", out["b"].shape[0]))
     out["start_seed"] = int(h.attrs.get("start_seed", -1))
     return out
 
 
-def write_checkpoint_npz(path, b, u, w, start_seed=0):
-    """Device-state checkpoint writer (npz container; same arrays as the reference's HDF5 files)."""
+def write_checkpoint_npz(path, b, u, w, start_seed=0, v=None):
+    """Device-state checkpoint writer (npz container; same arrays as the reference's HDF5 files; pass v for 3D)."""
+    extra = {} if v is None else {"v": np.asarray(v, np.float64)}
     np.savez_compressed(path, b=np.asarray(b, np.float64), u=np.asarray(u, np.float64), w=np.asarray(w, np.float64),
-                        start_seed=np.int64(start_seed), num_episodes=np.int64(np.asarray(b).shape[0]))
+                        start_seed=np.int64(start_seed), num_episodes=np.int64(np.asarray(b).shape[0]), **extra)

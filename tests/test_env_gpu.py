@@ -200,3 +200,32 @@ def test_rayleigh_sweep_statistics_match_reference_data(golden_dir):
         assert abs(ke[j].mean() - ref_ke.mean()) < 0.12 * ref_ke.mean(), (ra, ke[j].mean(), ref_ke.mean())
         lo, hi = ref_nu.min(), ref_nu.max()
         assert lo - 0.25 * (hi - lo) - 0.2 < nus[j].mean() < hi + 0.25 * (hi - lo) + 0.2, (ra, nus[j].mean(), lo, hi)
+
+
+def test_3d_env_contract(gym, tmp_path):
+    """rbc3D.py: spaces, info keys {t, step, nusselt}, time in free-fall units, full-state observation."""
+    ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
+    env = gym.make(ID3, state_shape=(8, 16, 16), heater_duration=0.0625, episode_length=0.5)
+    assert env.action_space.shape == (8, 8) and env.observation_space.shape == (4, 8, 16, 16)
+    assert np.all(env.observation_space.low[0] == 1) and np.all(env.observation_space.high[0] == np.float32(2.9))
+    obs, info = env.reset(seed=4)
+    assert obs.shape == (4, 8, 16, 16) and obs.dtype == np.float32 and set(info) == {"t", "step", "nusselt"}
+    assert info["t"] == 0.0 and info["step"] == 1 and abs(info["nusselt"] - 1.0) < 1e-2
+    obs, r, term, trunc, info = env.step(env.action_space.sample())
+    assert isinstance(r, float) and r == -info["nusselt"] and info["t"] == 0.25 and info["step"] == 2 and not trunc
+    _, _, _, trunc, info = env.step(None)
+    assert trunc and info["t"] == 0.5                      # episode_length reached
+    with pytest.raises(ValueError):
+        env.step(np.zeros((4, 4), np.float32))
+    o1, _ = env.reset(seed=4); o2, _ = env.reset()
+    assert np.array_equal(o1, o2)
+    # checkpoint path (npz container with v): the chosen episode comes back as the state
+    from rbc_gym.checkpoint import write_checkpoint_npz
+    f = env.unwrapped.sim.get_fields()
+    ck = str(tmp_path / "c3.npz")
+    write_checkpoint_npz(ck, f[0], f[1], f[3], v=f[2])
+    env.close()
+    env2 = gym.make(ID3, state_shape=(8, 16, 16), checkpoint=ck, checkpoint_idx=0)
+    o3, _ = env2.reset(seed=1)
+    assert np.array_equal(o3[0], f[0][0].astype(np.float32))
+    env2.close()
