@@ -68,6 +68,56 @@ def cpu_baseline(nsteps=6):
                       f"(README.md:62 publishes 0.12 s/step at 34 substeps on one Apple-silicon core)"}
 
 
+def bench3d(args, rank, local_rank, world, dev, dist, sharding, _native, np, torch):
+    """configs[4]: 3D 32x48x48, Ra=1e4, heater_duration 0.125, dt_solver 0.01 (13 RK3 substeps per env-step)."""
+    B = args.batch if args.batch != 1024 else 32
+    K, W = args.steps, args.warmup
+    sim = _native.NativeSim3D(batch=B, device=local_rank, shape=(32, 48, 48), ra=args.ra)
+    stream = torch.cuda.current_stream(dev)
+    sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)
+    start, count = sharding.shard(world * B, world, rank)
+    sim.reset(sharding.env_seeds(1234, start, count))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    actions = (torch.rand((K + W, B, 8, 8), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).contiguous()
+    stride = B * 64 * 4
+    for n in range(W):
+        sim.step_dev(actions.data_ptr() + n * stride)
+    sim.set_profiling(K)
+    torch.cuda.synchronize(dev)
+    sharding.barrier(dist if world > 1 else None)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for n in range(K):
+        sim.step_dev(actions.data_ptr() + (W + n) * stride)
+    torch.cuda.synchronize(dev)
+    sharding.barrier(dist if world > 1 else None)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ms = sim.profile_read(K)
+    nan_envs = int(sim.get_flags().sum())
+    nu = sim.get_nusselt()
+    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=dev, dist=dist if world > 1 else None)
+    if rank == 0:
+        alg = sim.algorithmic_bytes_per_env_step() * B
+        avg = float(np.mean(ms)) if len(ms) else float("nan")
+        ach = alg / (avg * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "env-steps/sec (batched 3D RBC 32x48x48 Ra=1e4)", "value": world * B * K / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[4]: batched 3D envs, batch={B} per GPU, grid 32x48x48, Ra={args.ra:g}, heater_duration 0.125 "
+                                   "(x t_ff=4) = 13 RK3 substeps per env-step, dt_solver 0.01", "global_batch": world * B,
+                       "parallelism": f"env-sharded x{world} (no collective on the step path)"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rbc3 stage sequence (hydrostatic, 4x tendency, slab FFT, z sweep, inverse FFT, correct) x 39",
+                         "kernel_ms_avg": avg, "algorithmic_bytes_per_launch": alg,
+                         "note": "algorithmic bytes = 10*F*C*s per substep (F=4, C=73728, s=8) x 13 x batch; 'launch' = one env-step of the batch"},
+            "cpu_baseline": None, "nan_envs": nan_total, "mean_nusselt": float(np.mean(nu))}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +129,8 @@ def main():
                     help="comma list, e.g. 1e4,1e5,1e6: BASELINE.json configs[3] stress case; the GLOBAL batch is split "
                          "into contiguous equal parts, one Rayleigh number each (fixed dt=0.03 as in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dim", type=int, default=2, choices=(2, 3),
+                    help="3: BASELINE.json configs[4] (3D 32x48x48, Ra=1e4, 32 envs per GPU); the default line is the 2D configs[1]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +157,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
+    if args.dim == 3:
+        return bench3d(args, rank, local_rank, world, dev, dist, sharding, _native, np, torch)
     sim = _native.NativeSim(batch=B, device=local_rank, ra=args.ra)
     stream = torch.cuda.current_stream(dev)
     sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)

@@ -19,6 +19,7 @@ namespace {
 
 void factor2(int n, int &n1, int &n2)
 {
+    if (n == 32 || n == 48 || n == 64) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8)
     n1 = 1;
     for (int d = 1; d * d <= n; ++d)
         if (n % d == 0) n1 = d;

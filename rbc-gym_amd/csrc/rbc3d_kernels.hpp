@@ -303,6 +303,100 @@ __device__ inline void slab_dft(const double2 *src, double2 *dst, int lines, int
 
 struct FftPlan { int nx1, nx2, ny1, ny2; };
 
+// ---- register-blocked slab FFT for n = N1*8 (N1 in {4,6,8}: n = 32, 48, 64) ----------------------
+// Same two-factor Cooley-Tukey as slab_dft, but each work item holds a whole small DFT in registers
+// (N1 loads for N1 outputs, then 8 for 8) instead of re-reading LDS for every output.
+__device__ __forceinline__ void dft4(double *re, double *im)
+{
+    const double s0r = re[0] + re[2], s0i = im[0] + im[2], d0r = re[0] - re[2], d0i = im[0] - im[2];
+    const double s1r = re[1] + re[3], s1i = im[1] + im[3], d1r = re[1] - re[3], d1i = im[1] - im[3];
+    re[0] = s0r + s1r; im[0] = s0i + s1i;
+    re[1] = d0r + d1i; im[1] = d0i - d1r;
+    re[2] = s0r - s1r; im[2] = s0i - s1i;
+    re[3] = d0r - d1i; im[3] = d0i + d1r;
+}
+// DFT-6 by the prime-factor map n=(3a+2b)%6, k=(3c+4d)%6 (a,c<2; b,d<3): no twiddles
+__device__ __forceinline__ void dft6(double *re, double *im)
+{
+    double sr[3], si[3], dr[3], di[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int p0 = (2 * b) % 6, p1 = (3 + 2 * b) % 6;
+        sr[b] = re[p0] + re[p1]; si[b] = im[p0] + im[p1];
+        dr[b] = re[p0] - re[p1]; di[b] = im[p0] - im[p1];
+    }
+    rbc::dft3(sr[0], si[0], sr[1], si[1], sr[2], si[2]);
+    rbc::dft3(dr[0], di[0], dr[1], di[1], dr[2], di[2]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        re[(4 * d) % 6] = sr[d]; im[(4 * d) % 6] = si[d];
+        re[(3 + 4 * d) % 6] = dr[d]; im[(3 + 4 * d) % 6] = di[d];
+    }
+}
+template <int N1> __device__ __forceinline__ void dftN(double *re, double *im)
+{
+    if (N1 == 4) dft4(re, im);
+    else if (N1 == 6) dft6(re, im);
+    else rbc::dft8(re, im);
+}
+
+template <int N1>
+__device__ inline void slab_fft(double2 *A, double2 *T, int lines, int ls, int es, const double2 *tw, int sign)
+{
+    // stage 1 (in place): DFT-N1 over a for fixed (line, b2), times W_n^(b2 k1)
+    for (int item = threadIdx.x; item < lines * 8; item += blockDim.x) {
+        const int line = item >> 3, b2 = item & 7;
+        double2 *base = A + line * ls + b2 * es;
+        double re[N1], im[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) { const double2 x = base[8 * a * es]; re[a] = x.x; im[a] = x.y; }
+        if (sign < 0) dftN<N1>(re, im); else dftN<N1>(im, re);
+#pragma unroll
+        for (int k1 = 0; k1 < N1; ++k1) {
+            const double2 t = tw[b2 * k1];
+            const double ti = sign < 0 ? -t.y : t.y;
+            base[8 * k1 * es] = make_double2(re[k1] * t.x - im[k1] * ti, re[k1] * ti + im[k1] * t.x);
+        }
+    }
+    __syncthreads();
+    // stage 2 (A -> T): DFT-8 over b2 for fixed (line, k1) -> position k1 + N1*k2
+    for (int item = threadIdx.x; item < lines * N1; item += blockDim.x) {
+        const int line = item / N1, k1 = item - line * N1;
+        const double2 *src = A + line * ls + 8 * k1 * es;
+        double re[8], im[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const double2 x = src[b * es]; re[b] = x.x; im[b] = x.y; }
+        if (sign < 0) rbc::dft8(re, im); else rbc::dft8(im, re);
+        double2 *dst = T + line * ls + k1 * es;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) dst[N1 * k2 * es] = make_double2(re[k2], im[k2]);
+    }
+    __syncthreads();
+}
+
+// 2D transform of the slab in A (result back in A); falls back to the generic routine for other sizes
+__device__ inline void slab_fft2d(double2 *A, double2 *T, int nx, int ny, const FftPlan &pl, const double2 *twx, const double2 *twy,
+                                  int sign)
+{
+    // along x: lines = rows (stride nx, element stride 1); result in T
+    bool inT;
+    if (pl.nx2 == 8 && pl.nx1 == 6) { slab_fft<6>(A, T, ny, nx, 1, twx, sign); inT = true; }
+    else if (pl.nx2 == 8 && pl.nx1 == 4) { slab_fft<4>(A, T, ny, nx, 1, twx, sign); inT = true; }
+    else if (pl.nx2 == 8 && pl.nx1 == 8) { slab_fft<8>(A, T, ny, nx, 1, twx, sign); inT = true; }
+    else { slab_dft(A, A, ny, nx, pl.nx1, pl.nx2, nx, 1, twx, sign, T); inT = false; }
+    double2 *S = inT ? T : A, *D = inT ? A : T;
+    // along y: lines = columns (stride 1, element stride nx); result in D (fast path) or S (generic)
+    if (pl.ny2 == 8 && pl.ny1 == 6) slab_fft<6>(S, D, nx, 1, nx, twy, sign);
+    else if (pl.ny2 == 8 && pl.ny1 == 4) slab_fft<4>(S, D, nx, 1, nx, twy, sign);
+    else if (pl.ny2 == 8 && pl.ny1 == 8) slab_fft<8>(S, D, nx, 1, nx, twy, sign);
+    else { slab_dft(S, S, nx, ny, pl.ny1, pl.ny2, 1, nx, twy, sign, D); D = S; }
+    if (D != A) {
+        for (int idx = threadIdx.x; idx < nx * ny; idx += blockDim.x) A[idx] = D[idx];
+        __syncthreads();
+    }
+}
+
+
 // forward: rhs slab (divergence of U*/dts) -> 2D spectrum.  One workgroup per (env, k).
 __global__ void k3_rhs_fft(Geo3 g, FftPlan pl, const double *st, double2 *spec, double dts)
 {
@@ -325,8 +419,7 @@ __global__ void k3_rhs_fft(Geo3 g, FftPlan pl, const double *st, double2 *spec, 
         A[idx] = make_double2(d * rdt, 0.0);
     }
     __syncthreads();
-    slab_dft(A, A, ny, nx, pl.nx1, pl.nx2, nx, 1, twx, -1, T);     // along x (rows); in place is fine: stage 1 reads all before stage 2 writes
-    slab_dft(A, A, nx, ny, pl.ny1, pl.ny2, 1, nx, twy, -1, T);     // along y (columns)
+    slab_fft2d(A, T, nx, ny, pl, twx, twy, -1);
     double2 *o = spec + ((size_t)env * nz + k) * pln;
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx];
 }
@@ -369,8 +462,7 @@ __global__ void k3_ifft(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
     const double2 *in = spec + ((size_t)env * nz + k) * pln;
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) A[idx] = in[idx];
     __syncthreads();
-    slab_dft(A, A, nx, ny, pl.ny1, pl.ny2, 1, nx, twy, +1, T);
-    slab_dft(A, A, ny, nx, pl.nx1, pl.nx2, nx, 1, twx, +1, T);
+    slab_fft2d(A, T, nx, ny, pl, twx, twy, +1);
     const double sc = 1.0 / (double)pln;
     double *o = phi + ((size_t)env * nz + k) * pln;
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx].x * sc;

@@ -116,3 +116,19 @@ def test_masked_reset_batch_independence_and_nan(native, o3):
     assert list(s) == [2, 1, 2]
     assert not sim.step(act)
     assert list(sim.get_flags()) == [0, 1, 0]
+
+
+def test_fast_fft_sizes(native, o3):
+    """48 = 6x8 and 64 = 8x8 take the register-blocked slab FFT (dft6 / dft8 x dft8); the other tests
+    run 32 = 4x8 and the generic 24 = 4x6 path."""
+    shape, dom = (8, 48, 64), (2.0, 4 * np.pi, 5 * np.pi)
+    o = o3.Oracle3D(ra=8000.0, shape=shape, domain=dom, kick=0.1, dt_control=0.02)
+    o.reset_random(9)
+    sim = native.NativeSim3D(batch=1, shape=shape, domain=dom, ra=8000.0, dt_control=0.02)
+    sim.reset_from_arrays(*[x[None] for x in o.fields()])
+    for x, y in zip(sim.get_fields(), o.fields()):
+        assert np.abs(x[0] - y).max() < 1e-13
+    act = np.random.default_rng(4).uniform(-1, 1, (1, 8, 8)).astype(np.float32)
+    assert sim.step(act) and o.step(act[0])
+    for x, y in zip(sim.get_fields(), o.fields()):
+        assert rel_l2(x[0], y) < 1e-11
