@@ -13,6 +13,9 @@ struct rbc3_state {
     double2 *spec = nullptr;
     size_t fft_lds = 0;
     double tff = 1.0;
+    // one captured HIP graph per ping-pong parity of the standard env-step (39 stages is odd, so the
+    // starting buffer alternates): ~350 launches replayed as one graph launch
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -90,6 +93,8 @@ void destroy3d(rbc_handle *h)
 {
     rbc3_state *s = h->s3;
     if (!s) return;
+    for (auto &g : s->gexec)
+        if (g) (void)hipGraphExecDestroy(g);
     void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->actT, s->tab, s->dbg};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -149,10 +154,33 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
 
 int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last, bool timed)
 {
+    rbc3_state *s = h->s3;
     const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
+    const bool standard = (nsub == h->nsub) && (dt == h->dt_solver_eff) && (dt_last == h->dt_last) && !h->no_graph;
+    if (standard && actions_dev != h->d_actions)     // the graph reads the handle's own action buffer
+        HIP3(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->B * s->g.heaters * s->g.heaters * sizeof(float),
+                            hipMemcpyDeviceToDevice, h->stream));
     if (rec) HIP3(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
-    if (int rc = advance3d(h, actions_dev, nsub, dt, dt_last)) return rc;
-    if (int rc = output3d(h, nullptr)) return rc;
+    if (standard) {
+        const int par = s->cur;
+        if (!s->gexec[par]) {
+            hipGraph_t graph = nullptr;
+            HIP3(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+            int rc = advance3d(h, h->d_actions, nsub, dt, dt_last);
+            if (!rc) rc = output3d(h, nullptr);
+            hipError_t e = hipStreamEndCapture(h->stream, &graph);
+            s->cur = par;                               // capture executed nothing: undo the host-side flips
+            if (rc) return rc;
+            if (e != hipSuccess) return fail(RBC_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            HIP3(hipGraphInstantiate(&s->gexec[par], graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+        HIP3(hipGraphLaunch(s->gexec[par], h->stream));
+        s->cur = par ^ ((3 * nsub) & 1);
+    } else {
+        if (int rc = advance3d(h, actions_dev, nsub, dt, dt_last)) return rc;
+        if (int rc = output3d(h, nullptr)) return rc;
+    }
     if (rec) {
         HIP3(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
         h->ev_used++;
