@@ -140,10 +140,18 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
         for (int ph = 0; ph < 3; ++ph) {
             double *cur = s->st[s->cur], *nxt = s->st[s->cur ^ 1];
             hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
-            hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-            hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-            hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-            hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
+                const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
+                hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
+                hipLaunchKernelGGL(rbc3::k3_tend_march<1>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
+                hipLaunchKernelGGL(rbc3::k3_tend_march<2>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
+                hipLaunchKernelGGL(rbc3::k3_tend_march<3>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
+            } else {
+                hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            }
             if (int rc = project3d(h, nxt, (gam[ph] + zet[ph]) * d, nullptr)) return rc;
             s->cur ^= 1;
         }

@@ -265,6 +265,153 @@ __global__ void k3_tendency(Geo3 g, const double *cur, double *nxt, double *gm, 
     if (FIELD == 2 && k == nz - 1) nxt[(size_t)env * g.env_stride + 3 * (size_t)g.nc + c0 + nx * ny] = 0.0;   // top wall face
 }
 
+
+// ---- z-marching tendency kernels ---------------------------------------------------------------------
+// Thread (env, chunk, j, i) walks KC3 (=4) levels upward keeping its own column's z window and the carried
+// face fluxes in registers; only the horizontal neighbours of the current level are loaded (about 90 cached
+// loads per cell for all four fields instead of ~380 in the cell-per-thread kernels above, which remain the
+// generic / debug path).  Same arithmetic, same order of operations per cell.
+#ifndef RBC_KC3
+#define RBC_KC3 4
+#endif
+constexpr int KC3 = RBC_KC3;
+
+template <int FIELD>
+__global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, double *nxt, double *gm, const double *phy, const double *actT,
+                              const double *nu_kappa, double dt, double gam, double zet, int B)
+{
+    const int nx = g.nx, ny = g.ny, nz = g.nz, pl = nx * ny, nch = nz / KC3;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pl * nch * B) return;
+    const int env = t / (pl * nch), r0 = t - env * pl * nch, ch = r0 / pl, ij = r0 - ch * pl, j = ij / nx, i = ij - j * nx;
+    const int k0 = ch * KC3;
+    const double *sb = cur + (size_t)env * g.env_stride;
+    const double *b = sb, *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double nu = nu_kappa[2 * env], ka = nu_kappa[2 * env + 1];
+    const double rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
+    int xi[7], yj[7];
+    wrap7(i, nx, xi); wrap7(j, ny, yj);
+    auto A = [&](const double *f, int a, int bb, int kk) -> double { return f[(size_t)kk * pl + yj[bb + 3] * nx + xi[a + 3]]; };
+    auto Zc = [&](const double *f, int a, int bb, int kk) -> double { return A(f, a, bb, min(max(kk, 0), nz - 1)); };
+    auto Zw = [&](int a, int bb, int kk) -> double { return A(w, a, bb, min(max(kk, 0), nz)); };
+    auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
+    auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
+    const size_t foff = (FIELD == 3) ? 0 : ((FIELD == 0) ? (size_t)g.nc : ((FIELD == 1) ? 2 * (size_t)g.nc : 3 * (size_t)g.nc));
+    const size_t ebase = (size_t)env * g.env_stride + foff;
+    auto commit = [&](int k, double old, double G) {
+        const size_t o = ebase + (size_t)k * pl + ij;
+        const double gprev = gm[o];
+        nxt[o] = old + dt * (gam * G + zet * gprev);
+        gm[o] = G;
+    };
+
+    if (FIELD == 0 || FIELD == 1) {
+        // u (FIELD 0) and v (FIELD 1) are mirror images: `a` runs along the field's own face direction
+        const double *f = (FIELD == 0) ? u : v;             // advected component
+        const double *o2 = (FIELD == 0) ? v : u;            // the other horizontal component
+        const double rda = (FIELD == 0) ? rdx : rdy, rdb = (FIELD == 0) ? rdy : rdx;
+        // accessors in (along, across) coordinates
+        auto F = [&](const double *q, int da, int db, int kk) -> double { return (FIELD == 0) ? A(q, da, db, kk) : A(q, db, da, kk); };
+        auto Wl = [&](int da, int db, int kk) -> double { return (FIELD == 0) ? Zw(da, db, kk) : Zw(db, da, kk); };
+        const double *ph = phy + (size_t)env * g.nc;
+        double win[6];
+        for (int q = 0; q < 6; ++q) win[q] = F(f, 0, 0, min(max(k0 - 3 + q, 0), nz - 1));
+        double fb = 0.0, dwb = 0.0, fdn;
+        if (k0 > 0) {
+            const double wm = Wl(-1, 0, k0), wc = Wl(0, 0, k0);
+            fb = upw(sym4(Wl(-2, 0, k0), wm, wc, Wl(1, 0, k0)), zfL(win, k0, nz), zfR(win, k0, nz));
+            dwb = wc - wm;
+            fdn = win[2];
+        } else fdn = ghost_lo(win[3], 0.0);
+        for (int k = k0; k < k0 + KC3; ++k) {
+            for (int q = 0; q < 5; ++q) win[q] = win[q + 1];
+            win[5] = F(f, 0, 0, min(k + 3, nz - 1));
+            const double f0 = win[2];
+            // own-direction flux at centres a-1 and a
+            double q7[7];
+            for (int q = 0; q < 7; ++q) q7[q] = (q == 3) ? f0 : F(f, q - 3, 0, k);
+            const double fe = upw(sym4(q7[2], q7[3], q7[4], q7[5]), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const double fw = upw(sym4(q7[1], q7[2], q7[3], q7[4]), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            // cross flux at across-faces b+1 and b: other component interpolated along `a`, f biased across
+            double c7[7];
+            for (int q = 0; q < 7; ++q) c7[q] = (q == 3) ? f0 : F(f, 0, q - 3, k);
+            const double on_m = F(o2, -1, 1, k), on_c = F(o2, 0, 1, k), os_m = F(o2, -1, 0, k), os_c = F(o2, 0, 0, k);
+            const double fn = upw(sym4(F(o2, -2, 1, k), on_m, on_c, F(o2, 1, 1, k)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+            const double fs = upw(sym4(F(o2, -2, 0, k), os_m, os_c, F(o2, 1, 0, k)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            // vertical flux at face k+1
+            double ft = 0.0, dwt = 0.0, fup;
+            if (k + 1 < nz) {
+                const double wm = Wl(-1, 0, k + 1), wc = Wl(0, 0, k + 1);
+                ft = upw(sym4(Wl(-2, 0, k + 1), wm, wc, Wl(1, 0, k + 1)), zfL(win, k + 1, nz), zfR(win, k + 1, nz));
+                dwt = wc - wm;
+                fup = win[3];
+            } else fup = ghost_hi(f0, 0.0);
+            const double adv = (fe - fw) * rda + (fn - fs) * rdb + (ft - fb) * rdz;
+            const double vis = nu * (2.0 * ((q7[4] - f0) - (f0 - q7[2])) * rda * rda
+                                     + (((c7[4] - f0) * rdb + (on_c - on_m) * rda) - ((f0 - c7[2]) * rdb + (os_c - os_m) * rda)) * rdb
+                                     + (((fup - f0) * rdz + dwt * rda) - ((f0 - fdn) * rdz + dwb * rda)) * rdz);
+            const double G = vis - adv - (F(ph, 0, 0, k) - F(ph, -1, 0, k)) * rda;
+            commit(k, f0, G);
+            fb = ft; dwb = dwt; fdn = f0;
+        }
+    } else if (FIELD == 2) {
+        double win[6], au[6], eu[6], av[6], ev[6];   // w faces; u at x-faces i, i+1; v at y-faces j, j+1 (levels k-3..k+2)
+        for (int q = 0; q < 6; ++q) {
+            win[q] = Zw(0, 0, k0 - 3 + q);
+            au[q] = Zc(u, 0, 0, k0 - 4 + q); eu[q] = Zc(u, 1, 0, k0 - 4 + q);
+            av[q] = Zc(v, 0, 0, k0 - 4 + q); ev[q] = Zc(v, 0, 1, k0 - 4 + q);
+        }
+        // flux_ww at centre k0-1: needs faces k0-3..k0+2 = win
+        double fb = (k0 > 0) ? upw(zcS(win, k0 - 1, nz), zcL(win, k0 - 1, nz), zcR(win, k0 - 1, nz)) : 0.0;
+        for (int k = k0; k < k0 + KC3; ++k) {
+            for (int q = 0; q < 5; ++q) { win[q] = win[q + 1]; au[q] = au[q + 1]; eu[q] = eu[q + 1]; av[q] = av[q + 1]; ev[q] = ev[q + 1]; }
+            win[5] = Zw(0, 0, k + 3);                       // faces k-2..k+3 (centre k between win[2]|win[3])
+            au[5] = Zc(u, 0, 0, k + 2); eu[5] = Zc(u, 1, 0, k + 2); av[5] = Zc(v, 0, 0, k + 2); ev[5] = Zc(v, 0, 1, k + 2);   // levels k-3..k+2
+            const double w0 = win[2];
+            const double ft = upw(zcS(win, k, nz), zcL(win, k, nz), zcR(win, k, nz));
+            if (k == 0) { fb = ft; continue; }              // wall face: never evolves (nxt keeps 0)
+            double q7[7], c7[7];
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : A(w, q - 3, 0, k); c7[q] = (q == 3) ? w0 : A(w, 0, q - 3, k); }
+            const double fe = upw(zfS(eu, k, nz), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const double fw = upw(zfS(au, k, nz), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const double fn = upw(zfS(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+            const double fs = upw(zfS(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
+            const double vis = nu * ((((eu[3] - eu[2]) * rdz + (q7[4] - w0) * rdx) - ((au[3] - au[2]) * rdz + (w0 - q7[2]) * rdx)) * rdx
+                                     + (((ev[3] - ev[2]) * rdz + (c7[4] - w0) * rdy) - ((av[3] - av[2]) * rdz + (w0 - c7[2]) * rdy)) * rdy
+                                     + 2.0 * ((win[3] - w0) - (w0 - win[1])) * rdz * rdz);
+            commit(k, w0, vis - adv);
+            fb = ft;
+        }
+        if (k0 + KC3 == nz) nxt[(size_t)env * g.env_stride + 3 * (size_t)g.nc + (size_t)nz * pl + ij] = 0.0;   // top wall face
+        if (k0 == 0) { const size_t o = ebase + ij; nxt[o] = 0.0; gm[o] = 0.0; }                                // bottom wall face
+    } else {
+        double win[6];
+        for (int q = 0; q < 6; ++q) win[q] = Zc(b, 0, 0, k0 - 3 + q);
+        double fb = (k0 > 0) ? upw(A(w, 0, 0, k0), zfL(win, k0, nz), zfR(win, k0, nz)) : 0.0;
+        double bdn = (k0 > 0) ? win[2] : ghost_lo(win[3], bottom_T(g, actT + (size_t)env * g.heaters * g.heaters, i, j));
+        for (int k = k0; k < k0 + KC3; ++k) {
+            for (int q = 0; q < 5; ++q) win[q] = win[q + 1];
+            win[5] = Zc(b, 0, 0, k + 3);
+            const double b0 = win[2];
+            double q7[7], c7[7];
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : A(b, q - 3, 0, k); c7[q] = (q == 3) ? b0 : A(b, 0, q - 3, k); }
+            const double fe = upw(A(u, 1, 0, k), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const double fw = upw(A(u, 0, 0, k), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const double fn = upw(A(v, 0, 1, k), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+            const double fs = upw(A(v, 0, 0, k), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            double ft = 0.0, bup;
+            if (k + 1 < nz) { ft = upw(A(w, 0, 0, k + 1), zfL(win, k + 1, nz), zfR(win, k + 1, nz)); bup = win[3]; }
+            else bup = ghost_hi(b0, g.min_b);
+            const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
+            const double dif = ka * (((q7[4] - b0) - (b0 - q7[2])) * rdx * rdx + ((c7[4] - b0) - (b0 - c7[2])) * rdy * rdy
+                                     + ((bup - b0) - (b0 - bdn)) * rdz * rdz);
+            commit(k, b0, dif - adv);
+            fb = ft; bdn = b0;
+        }
+    }
+}
+
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------
 // data: [rows][n] complex (re,im interleaved), n = n1*n2, line stride `ls`, element stride `es`
 // (so the same routine does rows and columns).  out-of-place src -> dst.  sign=-1 forward, +1 inverse.

@@ -7,6 +7,7 @@ no MI355X is visible, constructing a simulation raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -80,6 +81,29 @@ class RbcError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and libc10_hip.so asks
+    for it by file name, so if librbc_hip.so pulled in /opt/rocm's copy first, a later `import torch` would
+    load a second HIP runtime into the process and see no GPUs.  When torch is installed (and not yet
+    imported) preload its copy, so both bind to one runtime whatever the import order.
+    RBC_HIP_SYSTEM_RUNTIME=1 skips this."""
+    if os.environ.get("RBC_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                      # fall back to the system runtime
+
+
 def load_library(path=None):
     """Load librbc_hip.so and bind every declared symbol.  Raises if the library is absent:
     the product path never falls back to a CPU implementation."""
@@ -91,6 +115,7 @@ def load_library(path=None):
         raise ImportError(
             f"librbc_hip.so not found at {p}: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). rbc_gym has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
