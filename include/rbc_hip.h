@@ -83,6 +83,14 @@ int  rbc_synchronize(rbc_handle *h);
 /* per-env Rayleigh numbers (Ra sweep); ra[B] host pointer.  nu, kappa per api:40-41 */
 int  rbc_set_rayleigh(rbc_handle *h, const double *ra);
 
+/* RBCNormalizeObservation (wrappers/rbc_normalize_observation.py:66-74) fused into the observation write of
+   the 2D step kernel: obs[c] = maxval * (2 * (obs[c] - min_vals[c]) / (max_vals[c] - min_vals[c]) - 1), evaluated
+   in float32 in exactly that order on the float32-rounded sample, the python-float bounds rounded to float32 where
+   numpy rounds them (bit-identical to the numpy wrapper), then
+   clipped to [-maxval, maxval] if clip != 0.  nch <= 5 channels (b,u,w,pHY',pNHS); channels >= nch stay raw;
+   nch = 0 switches the transform off.  Takes effect from the next reset/step; rbc_get_state is never transformed. */
+int  rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip);
+
 /* initialize_simulation (api:17-70).  mask[B] (NULL = all): which envs to reset.
    Random IC (rbc_sim2D.jl:163-171) from the library's counter-based RNG, seeds[B].        */
 int  rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds);

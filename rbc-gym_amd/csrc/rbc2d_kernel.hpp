@@ -78,7 +78,21 @@ struct Params2D {
     int mode;
     int write_state;
     int obs_nx, obs_nz;
+    int obs_norm, obs_clip;    // rbc_set_obs_normalization: channels [0, obs_norm) of obs are normalised
+    float obs_min[5], obs_rng[5], obs_maxval;
 };
+
+// RBCNormalizeObservation.observation (rbc_normalize_observation.py:66-74) on one float32 sample: the same
+// float32 operations in the same order as the numpy expression (no contraction), so results are bit-identical.
+__device__ __forceinline__ float obs_value(const Params2D &P, int c, double x)
+{
+    float o = (float)x;
+    if (c < P.obs_norm) {
+        o = __fmul_rn(P.obs_maxval, __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(o, P.obs_min[c])), P.obs_rng[c]), 1.0f));
+        if (P.obs_clip) o = fminf(fmaxf(o, -P.obs_maxval), P.obs_maxval);
+    }
+    return o;
+}
 
 // ------------------------------------------------------------------------------------------
 // counter-based normal deviates (same construction as the test oracle's rbco_normal)
@@ -947,8 +961,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             const int k = k0 + r;
             if (xs && (k % stz) == 0) {
                 const size_t o = (size_t)(k / stz) * P.obs_nx + (i / stx);
-                ob[o] = (float)bn[r]; ob[och + o] = (float)un[r]; ob[2 * och + o] = (float)wn[r];
-                ob[3 * och + o] = (float)phy[r]; ob[4 * och + o] = (float)ph[r];
+                ob[o] = obs_value(P, 0, bn[r]); ob[och + o] = obs_value(P, 1, un[r]); ob[2 * och + o] = obs_value(P, 2, wn[r]);
+                ob[3 * och + o] = obs_value(P, 3, phy[r]); ob[4 * och + o] = obs_value(P, 4, ph[r]);
             }
         }
         if (P.write_state) {

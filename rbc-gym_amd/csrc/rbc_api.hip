@@ -40,6 +40,8 @@ struct rbc3_state;
 struct rbc_handle {
     rbc_config cfg;
     rbc3_state *s3 = nullptr;          // non-null for dim == 3 (rbc3d_host.hpp)
+    int obs_norm = 0, obs_clip = 0;    // rbc_set_obs_normalization
+    float obs_min[5] = {0, 0, 0, 0, 0}, obs_rng[5] = {1, 1, 1, 1, 1}, obs_maxval = 1.0f;
     bool no_march = false;             // RBC_NO_MARCH=1: use the cell-per-thread 3D tendency kernels (A/B and debug)
     bool no_graph = true;              // RBC_USE_GRAPH=1 replays the 3D env-step as a captured HIP graph (measured: +1 %, so off by default)
     int B = 0, nx = 0, nz = 0;
@@ -131,6 +133,8 @@ rbc::Params2D base_params(const rbc_handle *h)
     p.mode = rbc::MODE_STEP;
     p.write_state = h->cfg.write_state;
     p.obs_nx = h->cfg.obs_nx; p.obs_nz = h->cfg.obs_nz;
+    p.obs_norm = h->obs_norm; p.obs_clip = h->obs_clip; p.obs_maxval = h->obs_maxval;
+    for (int c = 0; c < 5; ++c) { p.obs_min[c] = h->obs_min[c]; p.obs_rng[c] = h->obs_rng[c]; }
     return p;
 }
 
@@ -501,6 +505,22 @@ static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t cha
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy2D(out, (size_t)nch * chan * sizeof(float), dev, total * chan * sizeof(float),
                         (size_t)nch * chan * sizeof(float), h->B, hipMemcpyDeviceToHost));
+    return RBC_OK;
+}
+
+int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (h->s3) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: the 3D observation is the raw state; normalise on the host");
+    if (nch < 0 || nch > 5) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: nch must be in [0, 5]");
+    if (nch > 0 && (!min_vals || !max_vals)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: NULL bounds");
+    for (int c = 0; c < nch; ++c) {
+        // the numpy expression divides by the python float (max - min) cast to float32
+        const float rng = (float)(max_vals[c] - min_vals[c]);
+        if (!(rng > 0.0f)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: max_vals must exceed min_vals");
+    }
+    for (int c = 0; c < nch; ++c) { h->obs_min[c] = (float)min_vals[c]; h->obs_rng[c] = (float)(max_vals[c] - min_vals[c]); }
+    h->obs_norm = nch; h->obs_clip = clip ? 1 : 0; h->obs_maxval = (float)maxval;
     return RBC_OK;
 }
 

@@ -156,6 +156,142 @@ except ImportError:                     # the stand-in
         def unwrapped(self):
             return self
 
+    class Wrapper(Env):
+        """gymnasium.Wrapper subset (1.x semantics: attributes are reached through `unwrapped` /
+        `get_wrapper_attr`, spaces and metadata are forwarded unless the wrapper overrides them)."""
+
+        def __init__(self, env):
+            self.env = env
+            self._observation_space = None
+            self._action_space = None
+
+        @property
+        def observation_space(self):
+            return self.env.observation_space if self._observation_space is None else self._observation_space
+
+        @observation_space.setter
+        def observation_space(self, space):
+            self._observation_space = space
+
+        @property
+        def action_space(self):
+            return self.env.action_space if self._action_space is None else self._action_space
+
+        @action_space.setter
+        def action_space(self, space):
+            self._action_space = space
+
+        @property
+        def metadata(self):
+            return self.env.metadata
+
+        @property
+        def render_mode(self):
+            return self.env.render_mode
+
+        @property
+        def spec(self):
+            return self.env.spec
+
+        @property
+        def np_random(self):
+            return self.env.np_random
+
+        @property
+        def np_random_seed(self):
+            return self.env.np_random_seed
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
+
+        def get_wrapper_attr(self, name):
+            if name in self.__dict__ or hasattr(type(self), name):
+                return getattr(self, name)
+            if hasattr(self.env, "get_wrapper_attr"):
+                return self.env.get_wrapper_attr(name)
+            return getattr(self.env, name)
+
+        def reset(self, *, seed=None, options=None):
+            return self.env.reset(seed=seed, options=options)
+
+        def step(self, action):
+            return self.env.step(action)
+
+        def render(self):
+            return self.env.render()
+
+        def close(self):
+            return self.env.close()
+
+    class ObservationWrapper(Wrapper):
+        def reset(self, *, seed=None, options=None):
+            obs, info = self.env.reset(seed=seed, options=options)
+            return self.observation(obs), info
+
+        def step(self, action):
+            obs, reward, terminated, truncated, info = self.env.step(action)
+            return self.observation(obs), reward, terminated, truncated, info
+
+        def observation(self, observation):
+            raise NotImplementedError
+
+    class RewardWrapper(Wrapper):
+        def step(self, action):
+            obs, reward, terminated, truncated, info = self.env.step(action)
+            return obs, self.reward(reward), terminated, truncated, info
+
+        def reward(self, reward):
+            raise NotImplementedError
+
+    class _Forwarded:
+        """attribute of a wrapper that reads through to the wrapped env until the wrapper assigns its own"""
+
+        def __set_name__(self, owner, name):
+            self.name = name
+
+        def __get__(self, obj, objtype=None):
+            if obj is None:
+                return self
+            own = obj.__dict__.get("_own_" + self.name, None)
+            return getattr(obj.env, self.name) if own is None else own
+
+        def __set__(self, obj, value):
+            obj.__dict__["_own_" + self.name] = value
+
+    class _VectorWrapper(_VectorEnv):
+        """gymnasium.vector.VectorWrapper subset."""
+        num_envs = _Forwarded()
+        single_observation_space = _Forwarded()
+        single_action_space = _Forwarded()
+        observation_space = _Forwarded()
+        action_space = _Forwarded()
+        metadata = _Forwarded()
+        render_mode = _Forwarded()
+        spec = _Forwarded()
+        closed = _Forwarded()
+
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):          # spaces, num_envs, ... of the wrapped vector env
+            if name.startswith("_") or name == "env":
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
+
+        def reset(self, *, seed=None, options=None):
+            return self.env.reset(seed=seed, options=options)
+
+        def step(self, actions):
+            return self.env.step(actions)
+
+        def close(self, **kw):
+            return self.env.close(**kw)
+
     class _Registry(dict):
         pass
 
@@ -183,6 +319,9 @@ except ImportError:                     # the stand-in
     class _GymNamespace:
         """Looks like the `gymnasium` module for the symbols rbc_gym and its users need."""
         Env = Env
+        Wrapper = Wrapper
+        ObservationWrapper = ObservationWrapper
+        RewardWrapper = RewardWrapper
         logger = _Logger()
         error = _Error
         registry = _Registry()
@@ -193,6 +332,7 @@ except ImportError:                     # the stand-in
 
         class vector:
             VectorEnv = _VectorEnv
+            VectorWrapper = _VectorWrapper
 
         class envs:
             class registration:

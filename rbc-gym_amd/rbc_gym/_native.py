@@ -46,6 +46,7 @@ SYMBOLS = {
     "rbc_get_stream": (_vp, [_vp]),
     "rbc_synchronize": (C.c_int, [_vp]),
     "rbc_set_rayleigh": (C.c_int, [_vp, _dp]),
+    "rbc_set_obs_normalization": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int]),
     "rbc_reset": (C.c_int, [_vp, _u8p, _u64p]),
     "rbc_reset_from_arrays": (C.c_int, [_vp, _u8p, _dp, _dp, _dp]),
     "rbc_step": (C.c_int, [_vp, _fp]),
@@ -195,6 +196,16 @@ class NativeSim:
     def set_rayleigh(self, ra):
         r = np.ascontiguousarray(np.broadcast_to(np.asarray(ra, np.float64), (self.B,)))
         self._check(self.lib.rbc_set_rayleigh(self.h, _ptr(r, _dp)))
+
+    def set_obs_normalization(self, min_vals=None, max_vals=None, maxval=1.0, clip=False):
+        """RBCNormalizeObservation fused into the kernel's observation write; None switches it off."""
+        if min_vals is None:
+            self._check(self.lib.rbc_set_obs_normalization(self.h, None, None, 0, 1.0, 0))
+            return
+        lo = np.ascontiguousarray(min_vals, np.float64)
+        hi = np.ascontiguousarray(max_vals, np.float64)
+        assert lo.shape == hi.shape and lo.ndim == 1
+        self._check(self.lib.rbc_set_obs_normalization(self.h, _ptr(lo, _dp), _ptr(hi, _dp), int(lo.size), float(maxval), int(bool(clip))))
 
     # -- step_simulation ---------------------------------------------------------------------
     def _actions(self, actions):

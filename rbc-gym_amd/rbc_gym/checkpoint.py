@@ -238,3 +238,138 @@ def write_checkpoint_npz(path, b, u, w, start_seed=0, v=None):
     extra = {} if v is None else {"v": np.asarray(v, np.float64)}
     np.savez_compressed(path, b=np.asarray(b, np.float64), u=np.asarray(u, np.float64), w=np.asarray(w, np.float64),
                         start_seed=np.int64(start_seed), num_episodes=np.int64(np.asarray(b).shape[0]), **extra)
+
+
+# ---------------------------------------------------------------------------------------------
+# HDF5 writer: the same subset of the format the reference's files use (what HDF5.jl writes at
+# rbc_sim2D.jl:36-43,64-66): superblock v0, a symbol-table root group with two scalar int64
+# attributes, and contiguous little-endian float64 datasets.  Files written here open with
+# libhdf5 (h5py / HDF5.jl / h5dump) and with `_MiniHDF5`.
+# ---------------------------------------------------------------------------------------------
+def _pad8(b):
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _msg(mtype, body, flags=0):
+    body = _pad8(body)
+    return struct.pack("<HHB3x", mtype, len(body), flags) + body
+
+
+def _object_header_v1(msgs):
+    body = b"".join(msgs)
+    return struct.pack("<BxHII4x", 1, len(msgs), 1, len(body)) + body
+
+
+_DT_F64 = struct.pack("<B3BI", 0x11, 0x20, 0x3F, 0x00, 8) + struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+_DT_I64 = struct.pack("<B3BI", 0x10, 0x08, 0x00, 0x00, 8) + struct.pack("<HH", 0, 64)
+
+
+def _dataspace_v1(shape):
+    return struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", int(s)) for s in shape)
+
+
+def _attribute_v1(name, value):
+    nm = name.encode() + b"\0"
+    ds = _dataspace_v1(())
+    return (struct.pack("<BxHHH", 1, len(nm), len(_DT_I64), len(ds)) + _pad8(nm) + _pad8(_DT_I64) + _pad8(ds)
+            + struct.pack("<q", int(value)))
+
+
+def write_hdf5(path, datasets, attrs):
+    """datasets: {name: float64 ndarray} stored contiguously in C order under the root group;
+    attrs: {name: int} scalar int64 root attributes."""
+    names = sorted(datasets)                       # symbol-table entries are ordered by name
+    if len(names) > 8:
+        raise ValueError("the built-in HDF5 writer holds at most 8 datasets (one symbol-table node)")
+    arrays = {k: np.ascontiguousarray(datasets[k], dtype="<f8") for k in names}
+    # local heap data segment: "" at offset 0, then the names, each 8-byte aligned
+    heap_data, name_off = bytearray(8), {}
+    for k in names:
+        name_off[k] = len(heap_data)
+        heap_data += _pad8(k.encode() + b"\0")
+    free_off = len(heap_data)
+    heap_data += struct.pack("<QQ", 1, 32) + b"\0" * 16        # one free block (next = 1 "none", size 32)
+    heap_size = len(heap_data)
+
+    # fixed layout: superblock 0..96 | root header | heap header | heap data | B-tree node | SNOD | dataset headers | data
+    sb_size = 8 + 8 + 4 + 4 + 4 * 8 + 40       # = 96
+    root_msgs_wo_addr = None
+    attr_msgs = [_msg(0x000C, _attribute_v1(k, attrs[k])) for k in attrs]
+    root_hdr_size = 16 + len(_msg(0x0011, b"\0" * 16)) + sum(len(m) for m in attr_msgs)
+    a_root = sb_size
+    a_heap = a_root + root_hdr_size
+    a_heap_data = a_heap + 32
+    a_btree = a_heap_data + heap_size
+    btree_size = 24 + (2 * 16 + 1) * 8 + 2 * 16 * 8            # header + keys + children for K=16
+    a_snod = a_btree + btree_size
+    snod_size = 8 + 8 * 40                                     # 2K entries, K=4
+    a_dset = a_snod + snod_size
+
+    def dataset_header(arr, addr):
+        return _object_header_v1([
+            _msg(0x0001, _dataspace_v1(arr.shape)),
+            _msg(0x0003, _DT_F64, flags=1),
+            _msg(0x0005, struct.pack("<BBBBI", 2, 2, 2, 1, 0)),       # fill value v2: alloc late, fill if-set, default
+            _msg(0x0008, struct.pack("<BBQQ", 3, 1, addr, arr.nbytes)),
+        ])
+
+    dset_hdr_size = {k: len(dataset_header(arrays[k], 0)) for k in names}
+    a_hdr, pos = {}, a_dset
+    for k in names:
+        a_hdr[k] = pos
+        pos += dset_hdr_size[k]
+    a_data = {}
+    pos = -(-pos // 2048) * 2048                 # data blocks start on a 2 KiB boundary like the reference's files
+    for k in names:
+        a_data[k] = pos
+        pos += arrays[k].nbytes
+    eof = pos
+
+    out = bytearray()
+    # superblock v0
+    out += b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBxHHI", 0, 0, 0, 0, 0, 8, 8, 4, 16, 0)
+    out += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+    out += struct.pack("<QQII", 0, a_root, 1, 0) + struct.pack("<QQ", a_btree, a_heap)   # root symbol-table entry
+    assert len(out) == sb_size
+    out += _object_header_v1([_msg(0x0011, struct.pack("<QQ", a_btree, a_heap))] + attr_msgs)
+    assert len(out) == a_heap
+    out += b"HEAP" + struct.pack("<B3xQQQ", 0, heap_size, free_off, a_heap_data)
+    out += heap_data
+    assert len(out) == a_btree
+    node = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF)
+    node += struct.pack("<QQQ", 0, a_snod, name_off[names[-1]])            # key0 | child0 | key1
+    out += node + b"\0" * (btree_size - len(node))
+    assert len(out) == a_snod
+    snod = b"SNOD" + struct.pack("<BxH", 1, len(names))
+    for k in names:
+        snod += struct.pack("<QQII16x", name_off[k], a_hdr[k], 0, 0)
+    out += snod + b"\0" * (snod_size - len(snod))
+    for k in names:
+        assert len(out) == a_hdr[k]
+        out += dataset_header(arrays[k], a_data[k])
+    out += b"\0" * (a_data[names[0]] - len(out))
+    with open(path, "wb") as f:
+        f.write(out)
+        for k in names:
+            f.write(arrays[k].tobytes())
+
+
+def write_checkpoint(path, b, u, w, start_seed=0, v=None):
+    """Write a checkpoint file in the reference's on-disk format (rbc_sim2D.jl:36-43,64-66; 3D: rbc_sim3D.jl writer):
+    root attributes num_episodes / start_seed and datasets b,u,[v],w of Julia shape (E, Nx, Ny, Nz[+1]), i.e.
+    (Nz[+1], Ny, Nx, E) in C order.  Inputs are (E, nz[+1], nx) for 2D or (E, nz[+1], ny, nx) for 3D.
+    A path ending in .npz writes the npz container instead."""
+    if str(path).endswith(".npz"):
+        return write_checkpoint_npz(path, b, u, w, start_seed=start_seed, v=v)
+    fields = {"b": b, "u": u, "w": w}
+    if v is not None:
+        fields["v"] = v
+    out = {}
+    for k, a in fields.items():
+        a = np.asarray(a, np.float64)
+        if a.ndim == 3:
+            a = a[:, :, None, :]                  # (E, nz, 1, nx)
+        if a.ndim != 4:
+            raise ValueError(f"field {k}: expected (E, nz, nx) or (E, nz, ny, nx), got {a.shape}")
+        out[k] = np.ascontiguousarray(np.moveaxis(a, 0, -1))      # (nz, ny, nx, E)
+    write_hdf5(str(path), out, {"num_episodes": out["b"].shape[-1], "start_seed": int(start_seed)})

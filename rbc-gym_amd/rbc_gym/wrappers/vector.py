@@ -1,0 +1,69 @@
+"""Batched wrappers for the device-batched vector env (rbc_gym.vector).  Same formulas as the single-env
+wrappers; the observation normalisation runs inside the step kernel (no extra pass over the observations, and
+device-resident policies read normalised observations straight from `device_views()["obs"]`)."""
+import numpy as np
+
+from .._gym import gym
+from .normalize import normalization_bounds, normalize_channels, reward_scale
+from .shaping import cell_distances
+
+
+class VectorRBCNormalizeObservation(gym.vector.VectorWrapper):
+    def __init__(self, env, heater_limit, maxval=1, u_limit=1.3, eps=0.3, clip=False):
+        super().__init__(env)
+        self.heater_limit, self.maxval, self.excursion_eps, self.clip = heater_limit, maxval, eps, clip
+        self.min_vals, self.max_vals = normalization_bounds(env.unwrapped, heater_limit, u_limit)
+        limit = maxval * (1 + eps)
+        shape = env.single_observation_space.shape
+        self.single_observation_space = gym.spaces.Box(low=-limit, high=limit, shape=shape, dtype=np.float32)
+        self.observation_space = gym.spaces.Box(low=-limit, high=limit, shape=(env.num_envs,) + tuple(shape), dtype=np.float32)
+        sim = getattr(env.unwrapped, "sim", None)
+        self.fused = sim is not None and hasattr(sim, "set_obs_normalization") and shape[0] <= len(self.min_vals)
+        if self.fused:
+            sim.set_obs_normalization(self.min_vals[:shape[0]], self.max_vals[:shape[0]], maxval, clip)
+
+    def _obs(self, obs):
+        if self.fused:
+            return obs                     # already normalised (and clipped) by the kernel
+        obs = normalize_channels(obs, self.min_vals, self.max_vals, self.maxval, channel_axis=1)
+        return np.clip(obs, -self.maxval, self.maxval) if self.clip else obs
+
+    def reset(self, *, seed=None, options=None):
+        obs, info = self.env.reset(seed=seed, options=options)
+        return self._obs(obs), info
+
+    def step(self, actions):
+        obs, reward, term, trunc, info = self.env.step(actions)
+        return self._obs(obs), reward, term, trunc, info
+
+    def close(self, **kw):
+        sim = getattr(self.env.unwrapped, "sim", None)
+        if self.fused and sim is not None and getattr(sim, "h", None):
+            sim.set_obs_normalization(None)
+        return self.env.close(**kw)
+
+
+class VectorRBCNormalizeReward(gym.vector.VectorWrapper):
+    def __init__(self, env):
+        super().__init__(env)
+        self.scale = reward_scale(env.unwrapped)
+
+    def step(self, actions):
+        obs, reward, term, trunc, info = self.env.step(actions)
+        return obs, (reward + self.scale) / (self.scale - 1), term, trunc, info
+
+
+class VectorRBCRewardShaping(gym.vector.VectorWrapper):
+    def __init__(self, env, shaping_weight):
+        super().__init__(env)
+        self.shaping_weight = shaping_weight
+        self.size_state = env.unwrapped.state_shape
+
+    def step(self, actions):
+        obs, reward, term, trunc, info = self.env.step(actions)
+        state = info["state"] if "state" in info else self.env.unwrapped.sim.get_state(3)
+        mid = state[:, 2, int(self.size_state[0] / 2) - 1]                    # UY channel, mid-height row: (B, nx)
+        cd = cell_distances(mid)
+        w = self.shaping_weight
+        info["cell_dist"] = cd
+        return obs, (1 - w) * reward + w * ((-cd + np.pi) / np.pi), term, trunc, info

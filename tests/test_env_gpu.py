@@ -229,3 +229,40 @@ def test_3d_env_contract(gym, tmp_path):
     o3, _ = env2.reset(seed=1)
     assert np.array_equal(o3[0], f[0][0].astype(np.float32))
     env2.close()
+
+
+def test_fused_observation_normalisation_is_bit_identical_to_the_numpy_wrapper(gym):
+    """rbc_set_obs_normalization (kernel-side RBCNormalizeObservation) against the host formula on the raw
+    observations of an identically driven second batch; also through device_views (zero-copy path)."""
+    from rbc_gym import wrappers as W
+    from rbc_gym.wrappers.normalize import normalize_channels
+    n = 6
+    raw = gym.make_vec(ID, num_envs=n, heater_duration=0.3)
+    fused = W.VectorRBCNormalizeObservation(gym.make_vec(ID, num_envs=n, heater_duration=0.3), heater_limit=0.75)
+    assert fused.fused and fused.num_envs == n
+    o_raw, _ = raw.reset(seed=3)
+    o_fus, _ = fused.reset(seed=3)
+    lo, hi = fused.min_vals, fused.max_vals
+    assert np.array_equal(o_fus, normalize_channels(o_raw.copy(), lo, hi, 1, channel_axis=1))
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        o_raw, r_raw, *_ , i_raw = raw.step(a)
+        o_fus, r_fus, *_, i_fus = fused.step(a)
+        assert np.array_equal(o_fus, normalize_channels(o_raw.copy(), lo, hi, 1, channel_axis=1))
+        assert np.array_equal(r_raw, r_fus)                                       # reward (Nusselt) is computed from raw fields
+        assert np.array_equal(i_raw["state"], i_fus["state"])                      # info["state"] stays raw
+    assert np.abs(o_fus[:, 0]).max() <= 1.0 and o_fus.dtype == np.float32
+    # clip variant with a tight velocity bound
+    clip = W.VectorRBCNormalizeObservation(gym.make_vec(ID, num_envs=n, heater_duration=0.3), heater_limit=0.0, u_limit=1e-3, clip=True)
+    o_c, _ = clip.reset(seed=3)
+    o_r, _ = raw.reset(seed=3)
+    want = np.clip(normalize_channels(o_r.copy(), clip.min_vals, clip.max_vals, 1, channel_axis=1), -1, 1)
+    assert np.array_equal(o_c, want) and np.abs(o_c).max() == 1.0
+    # single-env wrapper stack on the real env
+    env = W.RBCRewardShaping(W.RBCNormalizeReward(W.RBCNormalizeObservation(gym.make(ID, heater_duration=0.3), heater_limit=0.75)), 0.1)
+    obs, info = env.reset(seed=5)
+    obs, r, term, trunc, info = env.step(env.action_space.sample())
+    assert obs.dtype == np.float32 and np.abs(obs).max() < 1.3 and "cell_dist" in info and np.isfinite(r)
+    for e in (raw, fused, clip, env):
+        e.close()
