@@ -17,6 +17,7 @@
 //   transform) along x in LDS, tridiagonal (Thomas) solve along z per wavenumber, inverse FFT
 //   -> projection.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -250,7 +251,10 @@ struct Geo {
     // [scratch | NZ field rows | GUARD rows]: the scratch doubles as the guard below row 0, so every
     // stencil row offset is a compile-time immediate (values read from guards are selected away)
     static_assert(SCRATCH_DOUBLES >= GUARD * RS, "front scratch must cover the lower guard rows");
-    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH_DOUBLES + 3 * NCELL + GUARD * RS) * sizeof(double);
+    // the z solve parks pivot rows 16.. and one junction row (NX doubles) over the top guard rows; the little that
+    // does not fit extends the allocation
+    static constexpr int ZTAIL = ((NZ / 2 + 1 - 16) * NH + NX > GUARD * RS) ? (NZ / 2 + 1 - 16) * NH + NX - GUARD * RS : 0;
+    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH_DOUBLES + 3 * NCELL + GUARD * RS + ZTAIL) * sizeof(double);
     static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
     static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
 };
@@ -313,6 +317,17 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     lds_barrier();
     STAMP(5);
     tid = opaque(tid_in);
+    // Stage the pivot table of the z solve (NZ/2+1 rows x NH modes, L2-resident) into LDS that is idle during the
+    // projection: rows 0..15 over the reduction scratch (the column-scan partials of this stage are consumed), the
+    // rest over the top guard rows (their content is never used).  Loads are issued here, stored after the rhs.
+    constexpr int TROWS = NZ / 2 + 1, TSPLIT = 16, TN = TROWS * G::NH, TPER = (TN + G::NT - 1) / G::NT;
+    static_assert(TSPLIT * G::NH + NX <= SCRATCH_DOUBLES - 192, "pivot rows 0..15 + a junction row must fit the reduction scratch");
+    static_assert((TROWS - TSPLIT) * G::NH + NX <= G::GUARD * RS + G::ZTAIL, "remaining pivot rows + a junction row must fit above the fields");
+    double *tabA = const_cast<double *>(tw) + 192;
+    double *tabB = lds + NZ * RS - TSPLIT * G::NH;          // indexed with the global row number
+    double tstage[TPER];
+#pragma unroll
+    for (int q = 0; q < TPER; ++q) { const int idx = tid + q * G::NT; tstage[q] = tri_inv[min(idx, TN - 1)]; }
     // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl)
     {
         const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, ip1 = (i + 1 == NX) ? 0 : i + 1;
@@ -329,6 +344,11 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
             wlo = whi;
             lds[(k0 + r) * RS + FB + i] = d;
         }
+    }
+#pragma unroll
+    for (int q = 0; q < TPER; ++q) {
+        const int idx = tid + q * G::NT;
+        if (idx < TN) (idx < TSPLIT * G::NH ? tabA : tabB)[idx] = tstage[q];
     }
     lds_barrier();
     STAMP(6);
@@ -391,57 +411,87 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     const int tj = sw_up ? tid : tid - 128;
     const int tm = min(tj, NX - tj);
     const double cpf = rdz * rdz * (double)NX * ((tm == 0 || tm == NX / 2) ? 1.0 : 2.0);   // cp_k = tab_k * cpf
-    double *col = lds + FB + mode_pos(tj) + (sw_up ? 0 : (NZ - 1) * RS);
-    const int cstr = sw_up ? RS : -RS;
-    if (sw_up || sw_dn) {
+    double *colb = lds + FB + mode_pos(tj);
+    double *jctA = tabA + TSPLIT * G::NH, *jctB = tabB + TROWS * G::NH;
+    // Both sweeps are written with the direction as a compile-time constant and fully unrolled, so every LDS
+    // access is base + immediate and a row costs two loads, two fp64 ops and a store: the four active waves
+    // sit alone on their SIMDs and the phase is bound by their instruction count.
+    constexpr int BLK = 8;                                     // rows fetched ahead of the recurrence
+    static_assert(HALF % BLK == 0 && TSPLIT % BLK == 0, "z-sweep blocks must not straddle the table split");
+    auto fwd = [&](auto dir) {
+        constexpr int DIR = decltype(dir)::value;
         double y = 0.0;
-        constexpr int BLK = 8;
         double rr[BLK], tt[BLK];
 #pragma unroll
-        for (int j = 0; j < BLK; ++j) { rr[j] = col[j * cstr]; tt[j] = tri_inv[j * G::NH + tm]; }
-#pragma unroll 1
+        for (int j = 0; j < BLK; ++j) { rr[j] = colb[(DIR > 0 ? j : NZ - 1 - j) * RS]; tt[j] = tabA[j * G::NH + tm]; }
+#pragma unroll
         for (int s0 = 0; s0 < HALF; s0 += BLK) {
             double rn[BLK], tn[BLK];
-            const int sn = (s0 + BLK < HALF) ? s0 + BLK : s0;          // prefetch the next block (last: reload, unused)
+            if (s0 + BLK < HALF) {
 #pragma unroll
-            for (int j = 0; j < BLK; ++j) { rn[j] = col[(sn + j) * cstr]; tn[j] = tri_inv[(sn + j) * G::NH + tm]; }
-#pragma unroll
-            for (int j = 0; j < BLK; ++j) {
-                y = rr[j] * tt[j] - (tt[j] * cpf) * y;
-                col[(s0 + j) * cstr] = y;
-            }
-#pragma unroll
-            for (int j = 0; j < BLK; ++j) { rr[j] = rn[j]; tt[j] = tn[j]; }
-        }
-    }
-    lds_barrier();
-    STAMP(17);
-    if (sw_up || sw_dn) {
-        const double *mid = lds + FB + mode_pos(tj);
-        const double ya = mid[(HALF - 1) * RS], yb = mid[HALF * RS];
-        const double c = tri_inv[(HALF - 1) * G::NH + tm] * cpf;
-        const double jf = tri_inv[HALF * G::NH + tm];                 // 1/(1-c^2); 0 for the singular mean mode
-        double x = sw_up ? (ya - c * yb) * jf : (yb - c * ya) * jf;
-        if (tm == 0) x = sw_up ? ya : 0.0;                            // pin the mean mode (mean removed on output)
-        col[(HALF - 1) * cstr] = x;
-        constexpr int BLK = 8;
-#pragma unroll 1
-        for (int s0 = HALF - 2; s0 >= 0; s0 -= BLK) {
-            double yy[BLK], tt[BLK];
-#pragma unroll
-            for (int j = 0; j < BLK; ++j) {
-                const int sidx = max(s0 - j, 0);
-                yy[j] = col[sidx * cstr]; tt[j] = tri_inv[sidx * G::NH + tm];
-            }
-#pragma unroll
-            for (int j = 0; j < BLK; ++j) {
-                if (s0 - j >= 0) {
-                    x = yy[j] - (tt[j] * cpf) * x;
-                    col[(s0 - j) * cstr] = x;
+                for (int j = 0; j < BLK; ++j) {
+                    const int sidx = s0 + BLK + j;
+                    rn[j] = colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS];
+                    tn[j] = (sidx < TSPLIT ? tabA : tabB)[sidx * G::NH + tm];
                 }
             }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                y = tt[j] * (rr[j] - cpf * y);                       // y_k = (r_k - c y_{k-1}) / piv_k
+                colb[(DIR > 0 ? s0 + j : NZ - 1 - s0 - j) * RS] = y;
+            }
+            if (s0 + BLK < HALF) {
+#pragma unroll
+                for (int j = 0; j < BLK; ++j) { rr[j] = rn[j]; tt[j] = tn[j]; }
+            }
         }
-    }
+        (DIR > 0 ? jctA : jctB)[tj] = y;       // junction values travel through side rows: the other sweep overwrites in place
+    };
+    if (tid < 128) { if (sw_up) fwd(std::integral_constant<int, 1>{}); }
+    else if (tid < 256) { if (sw_dn) fwd(std::integral_constant<int, -1>{}); }
+    lds_barrier();
+    STAMP(17);
+    auto bwd = [&](auto dir) {
+        constexpr int DIR = decltype(dir)::value;
+        const double ya = jctA[tj], yb = jctB[tj];
+        const double c = (HALF - 1 < TSPLIT ? tabA : tabB)[(HALF - 1) * G::NH + tm] * cpf;
+        const double jf = (HALF < TSPLIT ? tabA : tabB)[HALF * G::NH + tm];   // 1/(1-c^2); 0 for the singular mean mode
+        double x = DIR > 0 ? (ya - c * yb) * jf : (yb - c * ya) * jf;
+        if (tm == 0) x = DIR > 0 ? ya : 0.0;                                  // pin the mean mode (mean removed on output)
+        colb[(DIR > 0 ? HALF - 1 : HALF) * RS] = x;
+        // rows HALF-2 .. 0 (sweep-local numbering), fetched BLK ahead; the first block is one row short
+        double yy[BLK], cc[BLK];
+#pragma unroll
+        for (int j = 0; j < BLK; ++j) {
+            const int sidx = HALF - 2 - j;
+            yy[j] = colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS];
+            cc[j] = (sidx < TSPLIT ? tabA : tabB)[sidx * G::NH + tm];
+        }
+#pragma unroll
+        for (int s0 = HALF - 2; s0 >= 0; s0 -= BLK) {
+            double yn[BLK], cn[BLK];
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                const int sidx = s0 - BLK - j;
+                if (sidx >= 0) {
+                    yn[j] = colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS];
+                    cn[j] = (sidx < TSPLIT ? tabA : tabB)[sidx * G::NH + tm];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                const int sidx = s0 - j;
+                if (sidx >= 0) {
+                    x = yy[j] - (cc[j] * cpf) * x;
+                    colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS] = x;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) { yy[j] = yn[j]; cc[j] = cn[j]; }
+        }
+    };
+    if (tid < 128) { if (sw_up) bwd(std::integral_constant<int, 1>{}); }
+    else if (tid < 256) { if (sw_dn) bwd(std::integral_constant<int, -1>{}); }
     lds_barrier();
     STAMP(18);
     tid = opaque(tid_in);
