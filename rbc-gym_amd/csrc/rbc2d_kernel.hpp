@@ -122,15 +122,15 @@ __device__ inline double normal_deviate(uint64_t seed, uint32_t field, uint32_t 
 // around the target: centre->face: target face sits between c and d; face->centre alike.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double left5(double a, double b, double c, double d, double e)
-{ return (2.0 * a - 13.0 * b + 47.0 * c + 27.0 * d - 3.0 * e) * (1.0 / 60.0); }
+{ return (2.0 / 60.0) * a - (13.0 / 60.0) * b + (47.0 / 60.0) * c + (27.0 / 60.0) * d - (3.0 / 60.0) * e; }
 __device__ __forceinline__ double right5(double b, double c, double d, double e, double f)
-{ return (-3.0 * b + 27.0 * c + 47.0 * d - 13.0 * e + 2.0 * f) * (1.0 / 60.0); }
+{ return (27.0 / 60.0) * c - (3.0 / 60.0) * b + (47.0 / 60.0) * d - (13.0 / 60.0) * e + (2.0 / 60.0) * f; }
 __device__ __forceinline__ double left3(double b, double c, double d)
-{ return (-b + 5.0 * c + 2.0 * d) * (1.0 / 6.0); }
+{ return (5.0 / 6.0) * c - (1.0 / 6.0) * b + (2.0 / 6.0) * d; }
 __device__ __forceinline__ double right3(double c, double d, double e)
-{ return (2.0 * c + 5.0 * d - e) * (1.0 / 6.0); }
+{ return (2.0 / 6.0) * c + (5.0 / 6.0) * d - (1.0 / 6.0) * e; }
 __device__ __forceinline__ double sym4(double b, double c, double d, double e)
-{ return (-b + 7.0 * c + 7.0 * d - e) * (1.0 / 12.0); }
+{ return (7.0 / 12.0) * (c + d) - (1.0 / 12.0) * (b + e); }
 
 // upwinded value: vel>0 takes the left-biased reconstruction (== upwind_biased_product/vel).
 // Both reconstructions are materialised (empty asm) so hipcc emits one v_cndmask pair instead of
@@ -680,6 +680,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     // rows / front scratch: whatever is read there is selected away by the wall-adjacent stencils
     auto off = [&](int rr, int f) -> int { return rr * RS + f; };
 
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63;       // first thread of this wave
+    const bool wall_wave = (wave0 / NX == 0) || ((wave0 + 63) / NX >= G::NC - 1);
     STAMP(0);
     for (int st = 0; st < nstage; ++st) {
         const int sub = st / 3, ph = st - 3 * sub;
@@ -695,232 +697,240 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         // stage (see opaque()) so they do not occupy registers through the Poisson phases
         const int ti = opaque(tid);
         const int c = ti / NX, i = ti - c * NX, k0 = c * CZ;
-        const bool bot = (c == 0), top = (c == G::NC - 1);
         const int ip1 = (i + 1 == NX) ? 0 : i + 1, ip2 = (ip1 + 1 == NX) ? 0 : ip1 + 1, ip3 = (ip2 + 1 == NX) ? 0 : ip2 + 1;
         const int im1 = (i == 0) ? NX - 1 : i - 1, im2 = (im1 == 0) ? NX - 1 : im1 - 1, im3 = (im2 == 0) ? NX - 1 : im2 - 1;
         const double *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
         const double *cc0 = lds + k0 * RS + i;
         const double *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
 
-        // ---- hydrostatic pressure anomaly ([OC] update_hydrostatic_pressure.jl) --------------
-        // pHY'[k] = pHY'[k+1] - b_face(k+1) dz.  G_u needs pHY'[i,k]-pHY'[i-1,k]
-        //         = -dz * sum_{k'>=k} mean(db[k'], db[k'+1]),  db[k] = b[i,k]-b[i-1,k].
-        // Pre-pass: the chunk totals; the u pass below walks DOWN its chunk and accumulates.
-        double db_top;   // db at the first row above the chunk (halo row for the top chunk)
-        {
-            {   // branch-free: the top chunk takes the Value-BC halo row, the others the row above
-                const double cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
-                const double hN = cN + ((P.min_b - cN) * rhz) * dz, hM = cM + ((P.min_b - cM) * rhz) * dz;
-                const double dn = cc0[off(CZ, FB)] - cm1[off(CZ, FB)];
-                db_top = top ? (hN - hM) : dn;
-            }
-            double acc = 0.0, dbu = db_top;
-#pragma unroll
-            for (int r = CZ - 1; r >= 0; --r) {
-                const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
-                acc += 0.5 * (d + dbu);
-                dbu = d;
-            }
-            scr[c * NX + i] = acc;
-        }
-        STAMP(15);
         const bool use_g0 = (ph != 0);      // zeta^1 = 0: the first stage of a substep needs no G^-
         const bool keep_g = (ph != 2);      // the tendencies of the last stage are never reused
-        double g0b[CZ], g0w[CZ];
-        lds_barrier();
-        STAMP(1);
-#pragma unroll
-        for (int r = 0; r < CZ; r += 2) {                                         // lands under the u pass
-            const dbl2 v = park_b[r / 2];
-            g0b[r] = use_g0 ? v.x : 0.0; g0b[r + 1] = use_g0 ? v.y : 0.0;
-        }
         double un[CZ], wn[CZ];
-        // ======================= u tendency (walks down the chunk) ==============================
-        {
-            double above = 0.0;
-            for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
-            double pacc = 0.0, dbu = db_top;
-            // z window of u around face k+1: rows k-2..k+3  (w0..w5), face between w2|w3
-            double w0, w1, w2, w3, w4, w5;
-            w0 = cc0[off(CZ - 3, FU)]; w1 = cc0[off(CZ - 2, FU)]; w2 = cc0[off(CZ - 1, FU)];
-            w3 = cc0[off(CZ, FU)]; w4 = cc0[off(CZ + 1, FU)]; w5 = cc0[off(CZ + 2, FU)];
-            // top face of the chunk (face k0+CZ): advecting w in x (Centered(4), periodic)
-            double wm_hi, wc_hi, fz_hi, uup;
-            {   // branch-free (clamped loads, selects): the top wall face carries no flux and w=0
-                wm_hi = top ? 0.0 : cm1[off(CZ, FW)]; wc_hi = top ? 0.0 : cc0[off(CZ, FW)];
-                const double wt = sym4(cm2[off(CZ, FW)], wm_hi, wc_hi, cp1[off(CZ, FW)]);
-                const double f = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
-                fz_hi = top ? 0.0 : f;
-                uup = top ? (w2 + ((0.0 - w2) * rhz) * dz) : w3;   // halo row above the top cell
-            }
-#pragma unroll
-            for (int r = CZ - 1; r >= 0; --r) {
-                // slide the window down: now around face k (rows k-3..k+2)
-                w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = w0; w0 = cc0[off(r - 3, FU)];
-                const double u0 = w3;
-                const double um3 = cm3[r * RS + FU], um2 = cm2[r * RS + FU], um1 = cm1[r * RS + FU];
-                const double up1 = cp1[r * RS + FU], up2 = cp2[r * RS + FU], up3 = cp3[r * RS + FU];
-                // flux_uu at centres i-1 and i  (advective_momentum_flux_Uu)
-                const double ut_w = sym4(um2, um1, u0, up1);
-                const double ut_e = sym4(um1, u0, up1, up2);
-                const double fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
-                const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
-                // bottom face k of this cell
-                double fz_lo, udn, wm_lo, wc_lo;
-                {   // the bottom wall row of w is identically 0 in LDS, so its flux vanishes by itself
-                    wm_lo = cm1[r * RS + FW]; wc_lo = cc0[r * RS + FW];
-                    const double wt = sym4(cm2[r * RS + FW], wm_lo, wc_lo, cp1[r * RS + FW]);
-                    // face k: 5th if 3<=k<=NZ-3, 3rd if 2<=k<=NZ-2, else 1st
-                    const bool ok5 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
-                    const bool ok3 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);
-                    fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
-                    const bool wall = (r == 0) && bot;
-                    fz_lo = wall ? 0.0 : fz_lo;
-                    udn = wall ? (u0 + ((u0 - 0.0) * rhz) * (-dz)) : w2;
+        // The three tendency passes exist twice: waves whose threads all sit in interior chunks (8 of the 12 at
+        // NZ=64, two per SIMD) run a copy in which bot/top are compile-time false, i.e. without the 3rd/1st-order
+        // fallbacks, wall selects and halo rows.  Both copies execute the same barriers.
+        auto tendencies = [&](auto wall_tag) __attribute__((always_inline)) {
+            constexpr bool WALL = decltype(wall_tag)::value;
+            const bool bot = WALL && (c == 0), top = WALL && (c == G::NC - 1);
+            // ---- hydrostatic pressure anomaly ([OC] update_hydrostatic_pressure.jl) --------------
+            // pHY'[k] = pHY'[k+1] - b_face(k+1) dz.  G_u needs pHY'[i,k]-pHY'[i-1,k]
+            //         = -dz * sum_{k'>=k} mean(db[k'], db[k'+1]),  db[k] = b[i,k]-b[i-1,k].
+            // Pre-pass: the chunk totals; the u pass below walks DOWN its chunk and accumulates.
+            double db_top;   // db at the first row above the chunk (halo row for the top chunk)
+            {
+                {   // branch-free: the top chunk takes the Value-BC halo row, the others the row above
+                    const double cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
+                    const double hN = cN + ((P.min_b - cN) * rhz) * dz, hM = cM + ((P.min_b - cM) * rhz) * dz;
+                    const double dn = cc0[off(CZ, FB)] - cm1[off(CZ, FB)];
+                    db_top = top ? (hN - hM) : dn;
                 }
-                const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
-                // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures, isotropic ScalarDiffusivity)
-                const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * P.rdx2
-                                         + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
-                // hydrostatic pressure gradient
-                const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
-                pacc += 0.5 * (d + dbu);
-                dbu = d;
-                const double dphy = -(pacc + above) * dz;
-                const double g = vis - adv - dphy * rdx;
-                if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = g;
-#if RBC_EXPERIMENT_NOG0
-                un[r] = u0 + dt * (gam * g);
-#else
-                un[r] = u0 + dt * (gam * g + zet * g0u[r]);
-                asm volatile("" : "+v"(un[r]));   // pin the update here: hipcc otherwise sinks it past the Poisson solve
-                g0u[r] = g;
-#endif
-                fz_hi = fz_lo; uup = u0; wm_hi = wm_lo; wc_hi = wc_lo;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        STAMP(2);
-        // ======================= b tendency (walks up) ===========================================
-#pragma unroll
-        for (int r = 0; r < CZ; r += 2) {                                         // lands under the b pass
-            const dbl2 v = park_w[r / 2];
-            g0w[r] = use_g0 ? v.x : 0.0; g0w[r + 1] = use_g0 ? v.y : 0.0;
-        }
-        {
-            double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
-            w0 = cc0[off(-3, FB)]; w1 = cc0[off(-2, FB)]; w2 = cc0[off(-1, FB)];
-            w3 = cc0[off(0, FB)]; w4 = cc0[off(1, FB)]; w5 = cc0[off(2, FB)];
-            double fz_lo = bot ? 0.0 : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
-            double bdn = bot ? (w3 + ((w3 - Tb) * rhz) * (-dz)) : w2;      // Value BC halo below the first cell
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) {
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = cc0[off(r + 3, FB)];   // now around face k+1
-                const double b0 = w2;
-                const double bm3 = cm3[r * RS + FB], bm2 = cm2[r * RS + FB], bm1 = cm1[r * RS + FB];
-                const double bp1 = cp1[r * RS + FB], bp2 = cp2[r * RS + FB], bp3 = cp3[r * RS + FB];
-                const double ui = cc0[r * RS + FU], ue = cp1[r * RS + FU];
-                const double fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
-                const double fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
-                double fz_hi, bup;
-                {
-                    const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
-                    const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
-                    const bool wall = (r == CZ - 1) && top;
-                    fz_hi = upwz(cc0[off(r + 1, FW)], w0, w1, w2, w3, w4, w5, ok5, ok3);
-                    fz_hi = wall ? 0.0 : fz_hi;
-                    bup = wall ? (b0 + ((P.min_b - b0) * rhz) * dz) : w3;
+                double acc = 0.0, dbu = db_top;
+    #pragma unroll
+                for (int r = CZ - 1; r >= 0; --r) {
+                    const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
+                    acc += 0.5 * (d + dbu);
+                    dbu = d;
                 }
-                const double adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
-                const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * P.rdx2 + ((bup - b0) - (b0 - bdn)) * P.rdz2);
-                const double g = dif - adv;
-                if (dbg) dg[(k0 + r) * NX + i] = g;
-#if RBC_EXPERIMENT_NOG0
-                bn[r] = b0 + dt * (gam * g);
-#else
-                bn[r] = b0 + dt * (gam * g + zet * g0b[r]);
-                asm volatile("" : "+v"(bn[r]));
-                g0b[r] = g;
-#endif
-                fz_lo = fz_hi; bdn = b0;
-                __builtin_amdgcn_sched_barrier(0);
+                scr[c * NX + i] = acc;
             }
-        }
-        if (keep_g) {
-#pragma unroll
-            for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0b[r]; v.y = g0b[r + 1]; park_b[r / 2] = v; }
-        }
-        STAMP(3);
-        if (!dbg) {
-            // every thread has finished reading the old b: its slot now parks the new u so that the
-            // heaviest pass below runs with one new-value array fewer in registers
+            STAMP(15);
+            double g0b[CZ], g0w[CZ];
             lds_barrier();
-            double *me = lds + k0 * RS + i;
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) me[r * RS + FB] = un[r];
-        }
-        // ======================= w tendency (faces k0..k0+7, walks up) ===========================
-        {
-            auto wld = [&](int rr) -> double { return (k0 + rr >= NZ) ? 0.0 : cc0[off(rr, FW)]; };
-            double w0, w1, w2, w3, w4, w5;   // w faces k-2..k+3 around centre k (between w2|w3)
-            w0 = wld(-3); w1 = wld(-2); w2 = wld(-1); w3 = wld(0); w4 = wld(1); w5 = wld(2);   // centre k0-1
-            double fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);   // flux_ww at centre k0-1
-            fz_lo = bot ? 0.0 : fz_lo;
-            // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
-            double a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
-            double e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
-#pragma unroll
-            for (int r = 0; r < CZ; ++r) {
-                if (r > 0) {
-                    a0 = a1; a1 = a2; a2 = a3; a3 = cc0[off(r + 1, FU)];
-                    e0 = e1; e1 = e2; e2 = e3; e3 = cp1[off(r + 1, FU)];
-                }
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = wld(r + 3);   // centre k: faces k-2..k+3
-                const double wc = w2;          // w at face k
-                // flux_ww at centre k: 5th if 2<=k<=NZ-3, 3rd if 1<=k<=NZ-2, else 1st
-                const bool c5 = ((r >= 2) || !bot) && ((r <= CZ - 3) || !top);
-                const bool c3 = ((r >= 1) || !bot) && ((r <= CZ - 2) || !top);
-#if RBC_SYMLEVEL
-                const bool c4 = c3;
-#else
-                const bool c4 = c5;
-#endif
-                const double fz_hi = upwz(symz(w1, w2, w3, w4, c4), w0, w1, w2, w3, w4, w5, c5, c3);
-                double g;
-                {
-#if RBC_SYMLEVEL
-                    const bool f4 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);       // 2<=k<=NZ-2
-#else
-                    const bool f4 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);       // 3<=k<=NZ-3
-#endif
-                    const double ut_w = symz(a0, a1, a2, a3, f4);
-                    const double ut_e = symz(e0, e1, e2, e3, f4);
-                    const double wm3 = cm3[r * RS + FW], wm2 = cm2[r * RS + FW], wm1 = cm1[r * RS + FW];
-                    const double wp1 = cp1[r * RS + FW], wp2 = cp2[r * RS + FW], wp3 = cp3[r * RS + FW];
-                    const double fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
-                    const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
-                    const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
-                    const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
-                                             + 2.0 * ((w3 - wc) - (wc - w1)) * P.rdz2);
-                    g = ((r == 0) && bot) ? 0.0 : (vis - adv);
-                }
-                if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = g;
-#if RBC_EXPERIMENT_NOG0
-                wn[r] = wc + dt * (gam * g);
-#else
-                wn[r] = wc + dt * (gam * g + zet * g0w[r]);
-                asm volatile("" : "+v"(wn[r]));
-                g0w[r] = g;
-#endif
-                fz_lo = fz_hi;
-                __builtin_amdgcn_sched_barrier(0);
+            STAMP(1);
+    #pragma unroll
+            for (int r = 0; r < CZ; r += 2) {                                         // lands under the u pass
+                const dbl2 v = park_b[r / 2];
+                g0b[r] = use_g0 ? v.x : 0.0; g0b[r + 1] = use_g0 ? v.y : 0.0;
             }
-        }
+            // ======================= u tendency (walks down the chunk) ==============================
+            {
+                double above = 0.0;
+                for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
+                double pacc = 0.0, dbu = db_top;
+                // z window of u around face k+1: rows k-2..k+3  (w0..w5), face between w2|w3
+                double w0, w1, w2, w3, w4, w5;
+                w0 = cc0[off(CZ - 3, FU)]; w1 = cc0[off(CZ - 2, FU)]; w2 = cc0[off(CZ - 1, FU)];
+                w3 = cc0[off(CZ, FU)]; w4 = cc0[off(CZ + 1, FU)]; w5 = cc0[off(CZ + 2, FU)];
+                // top face of the chunk (face k0+CZ): advecting w in x (Centered(4), periodic)
+                double wm_hi, wc_hi, fz_hi, uup;
+                {   // branch-free (clamped loads, selects): the top wall face carries no flux and w=0
+                    wm_hi = top ? 0.0 : cm1[off(CZ, FW)]; wc_hi = top ? 0.0 : cc0[off(CZ, FW)];
+                    const double wt = sym4(cm2[off(CZ, FW)], wm_hi, wc_hi, cp1[off(CZ, FW)]);
+                    const double f = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
+                    fz_hi = top ? 0.0 : f;
+                    uup = top ? (w2 + ((0.0 - w2) * rhz) * dz) : w3;   // halo row above the top cell
+                }
+    #pragma unroll
+                for (int r = CZ - 1; r >= 0; --r) {
+                    // slide the window down: now around face k (rows k-3..k+2)
+                    w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = w0; w0 = cc0[off(r - 3, FU)];
+                    const double u0 = w3;
+                    const double um3 = cm3[r * RS + FU], um2 = cm2[r * RS + FU], um1 = cm1[r * RS + FU];
+                    const double up1 = cp1[r * RS + FU], up2 = cp2[r * RS + FU], up3 = cp3[r * RS + FU];
+                    // flux_uu at centres i-1 and i  (advective_momentum_flux_Uu)
+                    const double ut_w = sym4(um2, um1, u0, up1);
+                    const double ut_e = sym4(um1, u0, up1, up2);
+                    const double fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
+                    const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
+                    // bottom face k of this cell
+                    double fz_lo, udn, wm_lo, wc_lo;
+                    {   // the bottom wall row of w is identically 0 in LDS, so its flux vanishes by itself
+                        wm_lo = cm1[r * RS + FW]; wc_lo = cc0[r * RS + FW];
+                        const double wt = sym4(cm2[r * RS + FW], wm_lo, wc_lo, cp1[r * RS + FW]);
+                        // face k: 5th if 3<=k<=NZ-3, 3rd if 2<=k<=NZ-2, else 1st
+                        const bool ok5 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
+                        const bool ok3 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);
+                        fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
+                        const bool wall = (r == 0) && bot;
+                        fz_lo = wall ? 0.0 : fz_lo;
+                        udn = wall ? (u0 + ((u0 - 0.0) * rhz) * (-dz)) : w2;
+                    }
+                    const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                    // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures, isotropic ScalarDiffusivity)
+                    const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * P.rdx2
+                                             + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
+                    // hydrostatic pressure gradient
+                    const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
+                    pacc += 0.5 * (d + dbu);
+                    dbu = d;
+                    const double dphy = -(pacc + above) * dz;
+                    const double g = vis - adv - dphy * rdx;
+                    if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = g;
+    #if RBC_EXPERIMENT_NOG0
+                    un[r] = u0 + dt * (gam * g);
+    #else
+                    un[r] = u0 + dt * (gam * g + zet * g0u[r]);
+                    asm volatile("" : "+v"(un[r]));   // pin the update here: hipcc otherwise sinks it past the Poisson solve
+                    g0u[r] = g;
+    #endif
+                    fz_hi = fz_lo; uup = u0; wm_hi = wm_lo; wc_hi = wc_lo;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            STAMP(2);
+            // ======================= b tendency (walks up) ===========================================
+    #pragma unroll
+            for (int r = 0; r < CZ; r += 2) {                                         // lands under the b pass
+                const dbl2 v = park_w[r / 2];
+                g0w[r] = use_g0 ? v.x : 0.0; g0w[r + 1] = use_g0 ? v.y : 0.0;
+            }
+            {
+                double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
+                w0 = cc0[off(-3, FB)]; w1 = cc0[off(-2, FB)]; w2 = cc0[off(-1, FB)];
+                w3 = cc0[off(0, FB)]; w4 = cc0[off(1, FB)]; w5 = cc0[off(2, FB)];
+                double fz_lo = bot ? 0.0 : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
+                double bdn = bot ? (w3 + ((w3 - Tb) * rhz) * (-dz)) : w2;      // Value BC halo below the first cell
+    #pragma unroll
+                for (int r = 0; r < CZ; ++r) {
+                    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = cc0[off(r + 3, FB)];   // now around face k+1
+                    const double b0 = w2;
+                    const double bm3 = cm3[r * RS + FB], bm2 = cm2[r * RS + FB], bm1 = cm1[r * RS + FB];
+                    const double bp1 = cp1[r * RS + FB], bp2 = cp2[r * RS + FB], bp3 = cp3[r * RS + FB];
+                    const double ui = cc0[r * RS + FU], ue = cp1[r * RS + FU];
+                    const double fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
+                    const double fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
+                    double fz_hi, bup;
+                    {
+                        const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
+                        const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
+                        const bool wall = (r == CZ - 1) && top;
+                        fz_hi = upwz(cc0[off(r + 1, FW)], w0, w1, w2, w3, w4, w5, ok5, ok3);
+                        fz_hi = wall ? 0.0 : fz_hi;
+                        bup = wall ? (b0 + ((P.min_b - b0) * rhz) * dz) : w3;
+                    }
+                    const double adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
+                    const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * P.rdx2 + ((bup - b0) - (b0 - bdn)) * P.rdz2);
+                    const double g = dif - adv;
+                    if (dbg) dg[(k0 + r) * NX + i] = g;
+    #if RBC_EXPERIMENT_NOG0
+                    bn[r] = b0 + dt * (gam * g);
+    #else
+                    bn[r] = b0 + dt * (gam * g + zet * g0b[r]);
+                    asm volatile("" : "+v"(bn[r]));
+                    g0b[r] = g;
+    #endif
+                    fz_lo = fz_hi; bdn = b0;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (keep_g) {
+    #pragma unroll
+                for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0b[r]; v.y = g0b[r + 1]; park_b[r / 2] = v; }
+            }
+            STAMP(3);
+            if (!dbg) {
+                // every thread has finished reading the old b: its slot now parks the new u so that the
+                // heaviest pass below runs with one new-value array fewer in registers
+                lds_barrier();
+                double *me = lds + k0 * RS + i;
+    #pragma unroll
+                for (int r = 0; r < CZ; ++r) me[r * RS + FB] = un[r];
+            }
+            // ======================= w tendency (faces k0..k0+7, walks up) ===========================
+            {
+                auto wld = [&](int rr) -> double { return (WALL && k0 + rr >= NZ) ? 0.0 : cc0[off(rr, FW)]; };
+                double w0, w1, w2, w3, w4, w5;   // w faces k-2..k+3 around centre k (between w2|w3)
+                w0 = wld(-3); w1 = wld(-2); w2 = wld(-1); w3 = wld(0); w4 = wld(1); w5 = wld(2);   // centre k0-1
+                double fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);   // flux_ww at centre k0-1
+                fz_lo = bot ? 0.0 : fz_lo;
+                // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
+                double a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
+                double e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
+    #pragma unroll
+                for (int r = 0; r < CZ; ++r) {
+                    if (r > 0) {
+                        a0 = a1; a1 = a2; a2 = a3; a3 = cc0[off(r + 1, FU)];
+                        e0 = e1; e1 = e2; e2 = e3; e3 = cp1[off(r + 1, FU)];
+                    }
+                    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = wld(r + 3);   // centre k: faces k-2..k+3
+                    const double wc = w2;          // w at face k
+                    // flux_ww at centre k: 5th if 2<=k<=NZ-3, 3rd if 1<=k<=NZ-2, else 1st
+                    const bool c5 = ((r >= 2) || !bot) && ((r <= CZ - 3) || !top);
+                    const bool c3 = ((r >= 1) || !bot) && ((r <= CZ - 2) || !top);
+    #if RBC_SYMLEVEL
+                    const bool c4 = c3;
+    #else
+                    const bool c4 = c5;
+    #endif
+                    const double fz_hi = upwz(symz(w1, w2, w3, w4, c4), w0, w1, w2, w3, w4, w5, c5, c3);
+                    double g;
+                    {
+    #if RBC_SYMLEVEL
+                        const bool f4 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);       // 2<=k<=NZ-2
+    #else
+                        const bool f4 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);       // 3<=k<=NZ-3
+    #endif
+                        const double ut_w = symz(a0, a1, a2, a3, f4);
+                        const double ut_e = symz(e0, e1, e2, e3, f4);
+                        const double wm3 = cm3[r * RS + FW], wm2 = cm2[r * RS + FW], wm1 = cm1[r * RS + FW];
+                        const double wp1 = cp1[r * RS + FW], wp2 = cp2[r * RS + FW], wp3 = cp3[r * RS + FW];
+                        const double fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
+                        const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
+                        const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                        const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
+                                                 + 2.0 * ((w3 - wc) - (wc - w1)) * P.rdz2);
+                        g = ((r == 0) && bot) ? 0.0 : (vis - adv);
+                    }
+                    if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = g;
+    #if RBC_EXPERIMENT_NOG0
+                    wn[r] = wc + dt * (gam * g);
+    #else
+                    wn[r] = wc + dt * (gam * g + zet * g0w[r]);
+                    asm volatile("" : "+v"(wn[r]));
+                    g0w[r] = g;
+    #endif
+                    fz_lo = fz_hi;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (dbg) return;
+            if (keep_g) {
+    #pragma unroll
+                for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0w[r]; v.y = g0w[r + 1]; park_w[r / 2] = v; }
+            }
+        };
+        if (wall_wave) tendencies(std::true_type{}); else tendencies(std::false_type{});
         if (dbg) return;
-        if (keep_g) {
-#pragma unroll
-            for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0w[r]; v.y = g0w[r + 1]; park_w[r / 2] = v; }
-        }
         STAMP(4);
         lds_barrier();   // every read of the old state is done
         {
