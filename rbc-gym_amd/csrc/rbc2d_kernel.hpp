@@ -353,10 +353,11 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     lds_barrier();
     STAMP(6);
     tid = opaque(tid_in);
-    // ---- forward FFT along x, two rows (2p, 2p+1) packed as one complex sequence ----------
+    // ---- forward FFT along x, two rows packed as one complex sequence: row p (real part) with its mirror
+    //      image NZ-1-p (imaginary part), see the z solve below ------------------------------------------
     if (tid < 12 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W96^(n2*k1)
         const int p = tid / 12, n2 = tid - 12 * p;
-        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
+        double *R = lds + p * RS + FB, *I = lds + (NZ - 1 - p) * RS + FB;
         double re[8], im[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) { re[n1] = R[12 * n1 + n2]; im[n1] = I[12 * n1 + n2]; }
@@ -376,7 +377,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     tid = opaque(tid_in);
     if (tid < 8 * (NZ / 2)) {           // pass B: DFT-12 over n2 for fixed k1 -> mode k1+8*k2 at 12*k1+k2
         const int p = tid / 8, k1 = tid - 8 * p;
-        double *R = lds + (2 * p) * RS + FB + 12 * k1, *I = R + RS;
+        double *R = lds + p * RS + FB + 12 * k1, *I = lds + (NZ - 1 - p) * RS + FB + 12 * k1;
         double re[12], im[12];
 #pragma unroll
         for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
@@ -388,21 +389,15 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     STAMP(8);
     tid = opaque(tid_in);
     // ---- z solve per wavenumber -------------------------------------------------------------
-    // (1) unpack the row pairing in place: row 2p <- 2*spectrum of row 2p, row 2p+1 <- 2*spectrum of
-    //     row 2p+1, each in half-complex form (Re of mode m at mode_pos(m), Im at mode_pos(NX-m));
-    //     the factor 2 is folded into the pivot table.  Modes 0 and NX/2 are already separated.
-    for (int idx = tid; idx < (NX / 2 - 1) * (NZ / 2); idx += G::NT) {
-        const int p = idx / (NX / 2 - 1), m = 1 + idx - (NX / 2 - 1) * p;
-        const int q1 = mode_pos(m), q2 = mode_pos(NX - m);
-        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
-        const double r1 = R[q1], r2 = R[q2], i1 = I[q1], i2 = I[q2];
-        R[q1] = r1 + r2; R[q2] = i1 - i2;
-        I[q1] = i1 + i2; I[q2] = r2 - r1;
-    }
-    lds_barrier();
-    STAMP(16);
-    tid = opaque(tid_in);
-    // (2) the 96 real tridiagonal systems (one per half-complex column), each eliminated from BOTH
+    // The packed transform Z_p[m] = A_p[m] + i A_{NZ-1-p}[m] (A_k = spectrum of row k) is never unpacked.  The
+    // operator is real and mirror symmetric in z, so eliminating from both walls applies, at step p, the SAME
+    // real recurrence to row p (sweeping up) and to row NZ-1-p (sweeping down): by linearity it can run on
+    // Re Z_p (stored in row p) and Im Z_p (stored in row NZ-1-p) directly, for all NX columns (column of mode
+    // m at mode_pos(m), eigenvalue index min(m, NX-m)).  Only the 2x2 junction between rows NZ/2-1 and NZ/2
+    // mixes the two sweeps: with P = y_up + i y_dn at mode m and P' at mode NX-m, conj(P') = y_up - i y_dn, so
+    //   x_up + i x_dn = jf [ P - i c conj(P') ]  =>  Re: jf (Re P[m] - c Im P[NX-m]),  Im: jf (Im P[m] - c Re P[NX-m]).
+    // The inverse transform of the packed solution returns phi_p (real part) and phi_{NZ-1-p} (imaginary part).
+    // The NX real tridiagonal recurrences per packed array, eliminated from BOTH
     //     walls at once: lanes 0..95 sweep rows 0..NZ/2-1 upward, lanes 128..223 sweep rows NZ-1..NZ/2
     //     downward (the operator is mirror symmetric, so both use the same pivots), they meet in a
     //     2x2 junction and substitute back outward.  y/x overwrite the column in place.
@@ -410,7 +405,8 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     const bool sw_up = tid < NX, sw_dn = (tid >= 128) && (tid < 128 + NX);
     const int tj = sw_up ? tid : tid - 128;
     const int tm = min(tj, NX - tj);
-    const double cpf = rdz * rdz * (double)NX * ((tm == 0 || tm == NX / 2) ? 1.0 : 2.0);   // cp_k = tab_k * cpf
+    const double cpf = rdz * rdz * (double)NX;                // cp_k = tab_k * cpf
+    const int tp = (tj == 0) ? 0 : NX - tj;                   // junction partner column (mode NX-m)
     double *colb = lds + FB + mode_pos(tj);
     double *jctA = tabA + TSPLIT * G::NH, *jctB = tabB + TROWS * G::NH;
     // Both sweeps are written with the direction as a compile-time constant and fully unrolled, so every LDS
@@ -453,7 +449,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     STAMP(17);
     auto bwd = [&](auto dir) {
         constexpr int DIR = decltype(dir)::value;
-        const double ya = jctA[tj], yb = jctB[tj];
+        const double ya = DIR > 0 ? jctA[tj] : jctA[tp], yb = DIR > 0 ? jctB[tp] : jctB[tj];
         const double c = (HALF - 1 < TSPLIT ? tabA : tabB)[(HALF - 1) * G::NH + tm] * cpf;
         const double jf = (HALF < TSPLIT ? tabA : tabB)[HALF * G::NH + tm];   // 1/(1-c^2); 0 for the singular mean mode
         double x = DIR > 0 ? (ya - c * yb) * jf : (yb - c * ya) * jf;
@@ -495,22 +491,10 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     lds_barrier();
     STAMP(18);
     tid = opaque(tid_in);
-    // (3) repack: Z[m] = A + iB, Z[NX-m] = conj(A) + i conj(B)
-    for (int idx = tid; idx < (NX / 2 - 1) * (NZ / 2); idx += G::NT) {
-        const int p = idx / (NX / 2 - 1), m = 1 + idx - (NX / 2 - 1) * p;
-        const int q1 = mode_pos(m), q2 = mode_pos(NX - m);
-        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
-        const double are = R[q1], aim = R[q2], bre = I[q1], bim = I[q2];
-        R[q1] = are - bim; I[q1] = aim + bre;
-        R[q2] = are + bim; I[q2] = bre - aim;
-    }
-    lds_barrier();
-    STAMP(9);
-    tid = opaque(tid_in);
     // ---- inverse FFT (swap re<->im roles) --------------------------------------------------
     if (tid < 8 * (NZ / 2)) {
         const int p = tid / 8, k1 = tid - 8 * p;
-        double *R = lds + (2 * p) * RS + FB + 12 * k1, *I = R + RS;
+        double *R = lds + p * RS + FB + 12 * k1, *I = lds + (NZ - 1 - p) * RS + FB + 12 * k1;
         double re[12], im[12];
 #pragma unroll
         for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
@@ -531,7 +515,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     tid = opaque(tid_in);
     if (tid < 12 * (NZ / 2)) {
         const int p = tid / 12, n2 = tid - 12 * p;
-        double *R = lds + (2 * p) * RS + FB, *I = R + RS;
+        double *R = lds + p * RS + FB, *I = lds + (NZ - 1 - p) * RS + FB;
         double re[8], im[8];
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) { re[k1] = R[12 * k1 + n2]; im[k1] = I[12 * k1 + n2]; }

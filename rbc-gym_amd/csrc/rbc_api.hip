@@ -82,9 +82,8 @@ void bind_kernel(rbc_handle *h)
 // Pivots of the z-direction operator of every Fourier mode (pressure solve):
 //   (phi[k-1] - 2 phi[k] + phi[k+1])/dz^2 - lam_x(m) phi[k] = r[k], mirror (Neumann) ends.
 // The kernel eliminates from both walls at once (the operator is mirror symmetric), so only the
-// pivots of rows 0..nz/2-1 are needed: tab[k][m] = 1/(piv_k * nx * f_m), where nx undoes the
-// unnormalised FFT pair and f_m = 2 for the modes whose spectra come out of the row unpacking
-// doubled (1 for m = 0, nx/2).  Row nz/2 holds the junction factor 1/(1 - c^2), c = o/piv_{nz/2-1}
+// pivots of rows 0..nz/2-1 are needed: tab[k][m] = 1/(piv_k * nx), where nx undoes the
+// unnormalised FFT pair.  Row nz/2 holds the junction factor 1/(1 - c^2), c = o/piv_{nz/2-1}
 // (0 for the singular mean mode m = 0, which the kernel pins instead).
 std::vector<double> tri_table(int nx, int nz, double lx, double lz)
 {
@@ -93,12 +92,11 @@ std::vector<double> tri_table(int nx, int nz, double lx, double lz)
     std::vector<double> tab((size_t)(half + 1) * nh);
     for (int m = 0; m < nh; ++m) {
         const double s = 2.0 * std::sin(m * pi / nx) / dx, lam = s * s;   // poisson_eigenvalues, Periodic
-        const double f = (m == 0 || m == nx / 2) ? 1.0 : 2.0;
         double piv = 0.0;
         for (int k = 0; k < half; ++k) {
             const double d = -((k == 0) ? 1.0 : 2.0) * o - lam;
             piv = (k == 0) ? d : d - o * o / piv;
-            tab[(size_t)k * nh + m] = 1.0 / (piv * nx * f);
+            tab[(size_t)k * nh + m] = 1.0 / (piv * nx);
         }
         const double c = o / piv;
         tab[(size_t)half * nh + m] = (m == 0) ? 0.0 : 1.0 / (1.0 - c * c);
