@@ -308,7 +308,8 @@ __device__ inline double block_sum(double v, double *scr, int tid)
 template <int NX, int NZ>
 __device__ __forceinline__ void project(double *__restrict__ lds, const double *__restrict__ tw,
                                         const double *__restrict__ tri_inv, double dts, double rdx, double rdz,
-                                        int tid_in, unsigned long long *stamp_acc, unsigned long long &stamp_last)
+                                        int tid_in, unsigned long long *stamp_acc, unsigned long long &stamp_last,
+                                        double (&un)[CZ], double (&wn)[CZ])
 {
     using G = Geo<NX, NZ>;
     constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
@@ -328,21 +329,22 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     double tstage[TPER];
 #pragma unroll
     for (int q = 0; q < TPER; ++q) { const int idx = tid + q * G::NT; tstage[q] = tri_inv[min(idx, TN - 1)]; }
-    // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl)
+    // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl).  un/wn = this thread's own U* cells
+    // (also in LDS for the neighbours); only the east u and the w face above the chunk are read.
     {
         const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, ip1 = (i + 1 == NX) ? 0 : i + 1;
         const bool top = (c == G::NC - 1);
         const double rdt = 1.0 / dts;
         const double *me = lds + k0 * RS;
-        double wlo = me[FW + i];
+        double ue[CZ];
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) ue[r] = me[r * RS + FU + ip1];
+        const double wtop = top ? 0.0 : me[CZ * RS + FW + i];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < CZ; ++r) {
-            const double *row = me + r * RS;
-            const double uc = row[FU + i], ue = row[FU + ip1];
-            const double whi = (r == CZ - 1 && top) ? 0.0 : row[RS + FW + i];
-            const double d = ((ue - uc) * rdx + (whi - wlo) * rdz) * rdt;
-            wlo = whi;
-            lds[(k0 + r) * RS + FB + i] = d;
+            const double whi = (r == CZ - 1) ? wtop : wn[r + 1];
+            lds[(k0 + r) * RS + FB + i] = ((ue[r] - un[r]) * rdx + (whi - wn[r]) * rdz) * rdt;
         }
     }
 #pragma unroll
@@ -530,14 +532,18 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     {
         const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, im1 = (i == 0) ? NX - 1 : i - 1;
         double *me = lds + k0 * RS;
+        double pc[CZ], pw[CZ];
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) { pc[r] = me[r * RS + FB + i]; pw[r] = me[r * RS + FB + im1]; }
         double pdn = (k0 > 0) ? me[-RS + FB + i] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < CZ; ++r) {
-            double *row = me + r * RS;
-            const double pc = row[FB + i], pw = row[FB + im1];
-            row[FU + i] -= (pc - pw) * rdx * dts;
-            if (k0 + r > 0) row[FW + i] -= (pc - pdn) * rdz * dts;
-            pdn = pc;
+            un[r] -= (pc[r] - pw[r]) * rdx * dts;
+            if (k0 + r > 0) wn[r] -= (pc[r] - pdn) * rdz * dts;
+            pdn = pc[r];
+            me[r * RS + FU + i] = un[r];
+            me[r * RS + FW + i] = wn[r];
         }
     }
 }
@@ -654,7 +660,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
         // set!'s incompressibility projection with unit time step ([OC] set_nonhydrostatic_model.jl)
-        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, stamp_acc, stamp_last);
+        double u0[CZ], w0[CZ];
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) { u0[r] = lds[(k0 + r) * RS + FU + i]; w0[r] = lds[(k0 + r) * RS + FW + i]; }
+        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, stamp_acc, stamp_last, u0, w0);
         // the b slot now holds phi (pNHS); b stays in registers
     } else {
         lds_barrier();
@@ -709,9 +719,13 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                     db_top = top ? (hN - hM) : dn;
                 }
                 double acc = 0.0, dbu = db_top;
-    #pragma unroll
+                double dcol[CZ], dmin[CZ];       // all loads first: hipcc otherwise serialises eight LDS round trips
+#pragma unroll
+                for (int r = 0; r < CZ; ++r) { dcol[r] = cc0[r * RS + FB]; dmin[r] = cm1[r * RS + FB]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
                 for (int r = CZ - 1; r >= 0; --r) {
-                    const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
+                    const double d = dcol[r] - dmin[r];
                     acc += 0.5 * (d + dbu);
                     dbu = d;
                 }
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             double g0b[CZ], g0w[CZ];
             lds_barrier();
             STAMP(1);
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < CZ; r += 2) {                                         // lands under the u pass
                 const dbl2 v = park_b[r / 2];
                 g0b[r] = use_g0 ? v.x : 0.0; g0b[r + 1] = use_g0 ? v.y : 0.0;
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                     fz_hi = top ? 0.0 : f;
                     uup = top ? (w2 + ((0.0 - w2) * rhz) * dz) : w3;   // halo row above the top cell
                 }
-    #pragma unroll
+#pragma unroll
                 for (int r = CZ - 1; r >= 0; --r) {
                     // slide the window down: now around face k (rows k-3..k+2)
                     w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = w0; w0 = cc0[off(r - 3, FU)];
@@ -793,7 +807,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             }
             STAMP(2);
             // ======================= b tendency (walks up) ===========================================
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < CZ; r += 2) {                                         // lands under the b pass
                 const dbl2 v = park_w[r / 2];
                 g0w[r] = use_g0 ? v.x : 0.0; g0w[r + 1] = use_g0 ? v.y : 0.0;
@@ -804,7 +818,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 w3 = cc0[off(0, FB)]; w4 = cc0[off(1, FB)]; w5 = cc0[off(2, FB)];
                 double fz_lo = bot ? 0.0 : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
                 double bdn = bot ? (w3 + ((w3 - Tb) * rhz) * (-dz)) : w2;      // Value BC halo below the first cell
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < CZ; ++r) {
                     w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = cc0[off(r + 3, FB)];   // now around face k+1
                     const double b0 = w2;
@@ -838,7 +852,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 }
             }
             if (keep_g) {
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0b[r]; v.y = g0b[r + 1]; park_b[r / 2] = v; }
             }
             STAMP(3);
@@ -847,7 +861,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 // heaviest pass below runs with one new-value array fewer in registers
                 lds_barrier();
                 double *me = lds + k0 * RS + i;
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < CZ; ++r) me[r * RS + FB] = un[r];
             }
             // ======================= w tendency (faces k0..k0+7, walks up) ===========================
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
                 double a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
                 double e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < CZ; ++r) {
                     if (r > 0) {
                         a0 = a1; a1 = a2; a2 = a3; a3 = cc0[off(r + 1, FU)];
@@ -909,7 +923,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             }
             if (dbg) return;
             if (keep_g) {
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0w[r]; v.y = g0w[r + 1]; park_w[r / 2] = v; }
             }
         };
@@ -920,9 +934,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         {
             double *me = lds + k0 * RS + i;
 #pragma unroll
-            for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = me[r * RS + FB]; me[r * RS + FW] = wn[r]; }
+            for (int r = 0; r < CZ; ++r) un[r] = me[r * RS + FB];          // U*_u comes back from its parking slot
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = un[r]; me[r * RS + FW] = wn[r]; }
         }
-        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last);
+        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last, un, wn);
         STAMP(12);
         if (st + 1 < nstage) {
             lds_barrier();   // phi reads done -> the b slot takes the new b
