@@ -103,7 +103,20 @@ __global__ void k3_hydrostatic(Geo3 g, const double *state, double *phy, int B)
     double acc = -(0.5 * (cN + halo)) * g.dz;
     p[(size_t)(g.nz - 1) * ncol + ij] = acc;
     double up = cN;
-    for (int k = g.nz - 2; k >= 0; --k) {
+    constexpr int BK = 8;                 // latency-bound column scan: fetch BK levels at a time
+    int k = g.nz - 2;
+    for (; k - BK + 1 >= 0; k -= BK) {
+        double c[BK];
+#pragma unroll
+        for (int q = 0; q < BK; ++q) c[q] = b[(size_t)(k - q) * ncol + ij];
+#pragma unroll
+        for (int q = 0; q < BK; ++q) {
+            acc = acc - (0.5 * (c[q] + up)) * g.dz;
+            p[(size_t)(k - q) * ncol + ij] = acc;
+            up = c[q];
+        }
+    }
+    for (; k >= 0; --k) {
         const double c = b[(size_t)k * ncol + ij];
         acc = acc - (0.5 * (c + up)) * g.dz;
         p[(size_t)k * ncol + ij] = acc;
@@ -580,8 +593,23 @@ __global__ void k3_thomas(Geo3 g, double2 *spec, const double *tab, int B)
     const int env = t / pln, mn = t - env * pln;
     double2 *s = spec + (size_t)env * g.nz * pln + mn;
     const double o = g.rdz * g.rdz;
+    // the sweeps are latency-bound (about one wave per SIMD): fetch BK levels ahead of the recurrence, the
+    // stores of one block overlap the loads of the next
+    constexpr int BK = 8;
     double yr = 0.0, yi = 0.0;
-    for (int k = 0; k < g.nz; ++k) {
+    int k = 0;
+    for (; k + BK <= g.nz; k += BK) {
+        double inv[BK]; double2 r[BK];
+#pragma unroll
+        for (int q = 0; q < BK; ++q) { inv[q] = tab[(size_t)(k + q) * pln + mn]; r[q] = s[(size_t)(k + q) * pln]; }
+#pragma unroll
+        for (int q = 0; q < BK; ++q) {
+            yr = r[q].x * inv[q] - (inv[q] * o) * yr;
+            yi = r[q].y * inv[q] - (inv[q] * o) * yi;
+            s[(size_t)(k + q) * pln] = make_double2(yr, yi);
+        }
+    }
+    for (; k < g.nz; ++k) {
         const double inv = tab[(size_t)k * pln + mn];
         const double2 r = s[(size_t)k * pln];
         yr = r.x * inv - (inv * o) * yr;
@@ -589,7 +617,18 @@ __global__ void k3_thomas(Geo3 g, double2 *spec, const double *tab, int B)
         s[(size_t)k * pln] = make_double2(yr, yi);
     }
     double xr = 0.0, xi = 0.0;
-    for (int k = g.nz - 1; k >= 0; --k) {
+    k = g.nz - 1;
+    for (; k - BK + 1 >= 0; k -= BK) {
+        double cp[BK]; double2 y[BK];
+#pragma unroll
+        for (int q = 0; q < BK; ++q) { cp[q] = tab[(size_t)(k - q) * pln + mn] * o; y[q] = s[(size_t)(k - q) * pln]; }
+#pragma unroll
+        for (int q = 0; q < BK; ++q) {
+            xr = y[q].x - cp[q] * xr; xi = y[q].y - cp[q] * xi;
+            s[(size_t)(k - q) * pln] = make_double2(xr, xi);
+        }
+    }
+    for (; k >= 0; --k) {
         const double cp = tab[(size_t)k * pln + mn] * o;
         const double2 y = s[(size_t)k * pln];
         xr = y.x - cp * xr; xi = y.y - cp * xi;
