@@ -35,7 +35,7 @@ def _batch_space(space, n):
 
 
 class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
-    metadata = {"render_modes": [], "autoreset_mode": "NextStep"}
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 10, "autoreset_mode": "NextStep"}
 
     def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
                  state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
@@ -147,6 +147,23 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
         """Advance all envs with actions already on the device ([B][heaters] float32); no host copy,
         no autoreset, asynchronous on the simulation's stream."""
         self.sim.step_dev(actions_device_ptr)
+
+    def render(self):
+        """One frame per env, as gymnasium's vector envs return them (a tuple): the temperature field through the
+        reference's colour map (rbc2D.py:236-240,258), from the float32 state already on the host side of the ABI."""
+        if self.render_mode is None:
+            gym.logger.warn("You are calling render method without specifying any render mode. "
+                            "You can specify the render_mode at initialization, ")
+            return None
+        if self.render_mode != "rgb_array":
+            raise ValueError(f"the batched env renders rgb_array frames only, not {self.render_mode!r}")
+        from .envs.rbc2D import colormap
+        temp = self.sim.get_state(1)[:, 0]                                   # (B, nz, nx)
+        frames = []
+        for t in temp:
+            data = np.flip(np.transpose(t), axis=1)
+            frames.append(colormap(data, vmin=1, vmax=2 + self.heater_limit).transpose(1, 0, 2))
+        return tuple(frames)
 
     def close(self, **kwargs):
         if getattr(self, "sim", None) is not None:

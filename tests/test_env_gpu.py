@@ -266,3 +266,22 @@ def test_fused_observation_normalisation_is_bit_identical_to_the_numpy_wrapper(g
     assert obs.dtype == np.float32 and np.abs(obs).max() < 1.3 and "cell_dist" in info and np.isfinite(r)
     for e in (raw, fused, clip, env):
         e.close()
+
+
+def test_vector_render_and_examples_run(gym, tmp_path):
+    import subprocess, sys, os
+    venv = gym.make_vec(ID, num_envs=3, heater_duration=0.3, render_mode="rgb_array")
+    venv.reset(seed=0)
+    frames = venv.render()
+    assert len(frames) == 3 and frames[0].shape == (64, 96, 3) and frames[0].dtype == np.uint8
+    single = gym.make(ID, heater_duration=0.3, render_mode="rgb_array")
+    single.reset(seed=0)                                   # vector env i gets seed + i: env 0 is the same episode
+    assert np.array_equal(single.render(), frames[0])
+    venv.close(); single.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = str(tmp_path / "train" / "ckpt_ra10000.h5")
+    for script, args in (("run_2D.py", ["3"]), ("run_vectorized.py", ["4", "3"]), ("timing.py", ["3"]), ("run_wrapped.py", ["3"]),
+                         ("run_checkpoint.py", [ck, "3"]), ("run_3D.py", ["2"])):
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", script), *args], capture_output=True, text=True,
+                             timeout=300, env={**os.environ, "RBC_SPINUP": "3"})
+        assert out.returncode == 0, out.stderr[-2000:]
