@@ -68,7 +68,7 @@ def cpu_baseline(nsteps=6):
                       f"(README.md:62 publishes 0.12 s/step at 34 substeps on one Apple-silicon core)"}
 
 
-def bench3d(args, rank, local_rank, world, dev, dist, sharding, _native, np, torch):
+def bench3d(args, rank, local_rank, world, dev, red_dev, dist, sharding, _native, np, torch):
     """configs[4]: 3D 32x48x48, Ra=1e4, heater_duration 0.125, dt_solver 0.01 (13 RK3 substeps per env-step)."""
     B = args.batch if args.batch != 1024 else 32
     K, W = args.steps, args.warmup
@@ -97,7 +97,7 @@ def bench3d(args, rank, local_rank, world, dev, dist, sharding, _native, np, tor
     ms = sim.profile_read(K)
     nan_envs = int(sim.get_flags().sum())
     nu = sim.get_nusselt()
-    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=dev, dist=dist if world > 1 else None)
+    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=red_dev, dist=dist if world > 1 else None)
     if rank == 0:
         alg = sim.algorithmic_bytes_per_env_step() * B
         avg = float(np.mean(ms)) if len(ms) else float("nan")
@@ -129,6 +129,8 @@ def main():
                     help="comma list, e.g. 1e4,1e5,1e6: BASELINE.json configs[3] stress case; the GLOBAL batch is split "
                          "into contiguous equal parts, one Rayleigh number each (fixed dt=0.03 as in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the N>1 flow with several ranks sharing one GPU")
     ap.add_argument("--dim", type=int, default=2, choices=(2, 3),
                     help="3: BASELINE.json configs[4] (3D 32x48x48, Ra=1e4, 32 envs per GPU); the default line is the 2D configs[1]")
     args = ap.parse_args()
@@ -150,15 +152,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.dist_backend == "gloo":          # rehearsal: ranks may outnumber the GPUs of the box
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    red_dev = dev if args.dist_backend == "nccl" else None      # gloo reduces host tensors
 
     B, K, W = args.batch, args.steps, args.warmup
     if args.dim == 3:
-        return bench3d(args, rank, local_rank, world, dev, dist, sharding, _native, np, torch)
+        return bench3d(args, rank, local_rank, world, dev, red_dev, dist, sharding, _native, np, torch)
     sim = _native.NativeSim(batch=B, device=local_rank, ra=args.ra)
     stream = torch.cuda.current_stream(dev)
     sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)
@@ -197,7 +205,7 @@ def main():
     nan_envs = int(flags.sum())
     nus, _ = sim.get_nusselt()
 
-    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=dev, dist=dist if world > 1 else None)
+    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=red_dev, dist=dist if world > 1 else None)
 
     if rank == 0:
         traffic, traffic_src = None, None
@@ -236,7 +244,8 @@ def main():
                          "kernel": "rbc2d_kernel<96,64>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = 10*F*C*s per RK3 substep (F=3,C=6144,s=8) x 50 x batch; the kernel "
-                                 "keeps the state in LDS for the whole control interval, so real HBM traffic is ~0.4 MB/env"},
+                                 "keeps the state in LDS for the whole control interval: real HBM traffic is ~0.4 MB/env of state and outputs "
+                                 "plus ~10 MB/env of G^- tendencies parked through L2 (write-through stores, reads served by L2)"},
             "cpu_baseline": cpu,
             "nan_envs": nan_total,
             "ra_sweep": ({"values": [float(x) for x in args.ra_sweep.split(",")],

@@ -35,3 +35,19 @@ def reduce_run(elapsed, nan_envs, device=None, dist=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def gather_observations(local_obs, dist=None):
+    """Optional exchange step when the policy lives on one GPU: all-gather of the per-rank
+    observation batches, rank-major, i.e. in global env order for contiguous equal shards.  `local_obs` is a torch
+    tensor -- e.g. `torch.as_tensor(venv.device_views()["obs"], device="cuda")`, zero-copy over the library's
+    buffer, so on the GPU box this is one RCCL all-gather over xGMI (8192 envs x 4.6 KB = 38 MB per step) with
+    no host hop.  Not on the step path: the solver itself never communicates."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_obs
+    world = dist.get_world_size()
+    local = local_obs.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out

@@ -46,7 +46,10 @@ def _worker(rank, world, port, q):
     res = _step_envs(range(start, start + count))
     sharding.barrier(dist)
     elapsed, nans = sharding.reduce_run(1.0 + rank, rank, dist=dist)     # rank-dependent inputs: MAX / SUM visible
-    q.put((rank, res, elapsed, nans))
+    import torch
+    local = torch.arange(start, start + count, dtype=torch.float32).reshape(count, 1, 1).expand(count, 3, 2).contiguous()
+    obs = sharding.gather_observations(local, dist)                       # optional policy-side exchange
+    q.put((rank, res, elapsed, nans, obs[:, 0, 0].tolist()))
     dist.destroy_process_group()
 
 
@@ -64,8 +67,9 @@ def test_two_ranks_reproduce_one_process():
         p.join(60)
         assert p.exitcode == 0
     merged = {}
-    for rank, res, elapsed, nans in got:
+    for rank, res, elapsed, nans, order in got:
         assert elapsed == 2.0 and nans == 1                 # max over ranks, sum over ranks
+        assert order == [0.0, 1.0, 2.0, 3.0]                # gathered observations arrive in global env order
         merged.update(res)
     serial = _step_envs(range(4))
     assert sorted(merged) == [0, 1, 2, 3]
