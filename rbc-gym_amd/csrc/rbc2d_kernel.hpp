@@ -41,6 +41,9 @@ enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENC
 #ifndef RBC_STAMPS
 #define RBC_STAMPS 0
 #endif
+#ifndef RBC_EXPERIMENT_NOPROJECT
+#define RBC_EXPERIMENT_NOPROJECT 0   // timing experiment only (WRONG numerics): skips the pressure projection
+#endif
 #ifndef RBC_EXPERIMENT_NOG0
 #define RBC_EXPERIMENT_NOG0 0   // timing experiment only (WRONG numerics): drops the G^- registers
 #endif
@@ -938,7 +941,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #pragma unroll
             for (int r = 0; r < CZ; ++r) { me[r * RS + FU] = un[r]; me[r * RS + FW] = wn[r]; }
         }
+#if RBC_EXPERIMENT_NOPROJECT
+        lds_barrier();          // timing experiment only (WRONG numerics): what the stage costs without the Poisson solve
+#else
         project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last, un, wn);
+#endif
         STAMP(12);
         if (st + 1 < nstage) {
             lds_barrier();   // phi reads done -> the b slot takes the new b
