@@ -285,3 +285,41 @@ def test_vector_render_and_examples_run(gym, tmp_path):
         out = subprocess.run([sys.executable, os.path.join(root, "examples", script), *args], capture_output=True, text=True,
                              timeout=300, env={**os.environ, "RBC_SPINUP": "3"})
         assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_from_rest_ensemble_lands_on_the_reference_attractor(golden_dir):
+    """Pin P2 on the product itself: the reference's checkpoint protocol (random kick 0.02, dt 0.03, zero action,
+    t = 600; scripts/create_checkpoints_2D.sh:18-20) run as a 256-member batch on the GPU, against the statistics of
+    the 40 Oceananigans episodes the reference ships (KE 0.0983448, Nu_state 3.99764, Nu_obs 4.19266,
+    bottom <b> rows 1.96119 / 1.88460 / 1.81012).  All 40 reference episodes sit on the two-roll-pair (k=2)
+    steady state; of 1024 members run here (scripts/ensemble_from_rest.py) 967 do, with KE 0.098344904 +- 2.1e-8
+    against the reference's 0.098344872 +- 1.0e-7, and 57 settle on a second stable state (k=1, KE 0.07852,
+    Nu 3.180), so the comparison is made on the k=2 members."""
+    import json
+    from rbc_gym import _native
+    ref = json.load(open(os.path.join(golden_dir, "oracle_ensemble_ra10000.json")))["reference"]
+    n = 256
+    sim = _native.NativeSim(batch=n, random_kick=0.02, write_state=0)
+    sim.reset(np.arange(n, dtype=np.uint64) + 4242)
+    zero = np.zeros((n, 12), np.float32)
+    for _ in range(400):
+        assert sim.step(zero)
+    b, u, w = sim.get_fields()
+    ke = 0.5 * ((u ** 2).mean((1, 2)) + (w[:, :64] ** 2).mean((1, 2)))
+    nus, nuo = sim.get_nusselt()
+    spec = np.abs(np.fft.rfft(w[:, 32], axis=1))
+    on = (spec[:, 1:].argmax(1) + 1) == 2
+    assert on.sum() > 0.85 * n
+    assert np.all(np.abs(ke[~on] - 0.0785188) < 1e-5)                      # the other members: the k=1 steady state
+    m = int(on.sum())
+    for mine, key in ((ke[on], "ke"), (nus[on], "nu_state"), (nuo[on], "nu_obs")):
+        sem = np.hypot(mine.std(ddof=1) / np.sqrt(m), ref[f"{key}_sem"])
+        z = (mine.mean() - ref[f"{key}_mean"]) / sem
+        assert abs(z) < 4.0, (key, mine.mean(), ref[f"{key}_mean"], z)
+    assert abs(ke[on].mean() - ref["ke_mean"]) / ref["ke_mean"] < 2e-6
+    assert ke[on].std() / ke[on].mean() < 2e-5                             # "40 independent random ICs agree to 2e-5"
+    prof = b[on].mean((0, 2))
+    assert np.allclose(prof[:3], [1.96119, 1.88460, 1.81012], atol=1e-5)
+    assert np.allclose(prof[-3:][::-1], 3.0 - np.array([1.96119, 1.88460, 1.81012]), atol=1e-5)
+    assert abs(b.mean() - 1.5) < 1e-6
+    sim.close()
