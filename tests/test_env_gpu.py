@@ -323,3 +323,30 @@ def test_from_rest_ensemble_lands_on_the_reference_attractor(golden_dir):
     assert np.allclose(prof[-3:][::-1], 3.0 - np.array([1.96119, 1.88460, 1.81012]), atol=1e-5)
     assert abs(b.mean() - 1.5) < 1e-6
     sim.close()
+
+
+def test_ra_sweep_ensembles_match_the_reference_episode_statistics():
+    """Pin P3, quantitatively, on the product: the reference's checkpoint protocol at the seven Rayleigh numbers it ships
+    episodes for (1e4 ... 1e7; 40 episodes each), 64 GPU members per Ra in one batch, z-tests of the ensemble means
+    against the episodes' (scripts/ensemble_ra_sweep.py; its 128-member run: KE 0.1126/0.1310/0.1436/0.1606/0.1697 vs
+    the reference's 0.1117/0.1305/0.1434/0.1619/0.1699 at Ra = 3e4 ... 3e6, all |z| < 0.5; Ra = 1e7, the most
+    under-resolved case, 0.2001 vs 0.1952, z = 4.0)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ensemble_ra_sweep", os.path.join(root, "scripts", "ensemble_ra_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref, got = mod.reference_stats(), mod.run(per=64, seed0=31337)
+
+    def z(ra, key):
+        a, r = got[ra][key], ref[ra][key]
+        return (a.mean() - r.mean()) / np.hypot(a.std(ddof=1) / np.sqrt(a.size), r.std(ddof=1) / np.sqrt(r.size))
+
+    for ra in (30000, 100000, 300000, 1000000, 3000000):
+        assert abs(z(ra, "ke")) < 4.0, (ra, got[ra]["ke"].mean(), ref[ra]["ke"].mean())
+        assert abs(z(ra, "nusselt_state")) < 4.0 and abs(z(ra, "wmax")) < 4.5 and abs(z(ra, "umax")) < 4.5, ra
+    assert abs(got[3000000]["ke"].mean() / ref[3000000]["ke"].mean() - 1) < 0.01      # the narrowest chaotic distribution (std 1.4 %)
+    assert abs(got[10000000]["ke"].mean() / ref[10000000]["ke"].mean() - 1) < 0.05
+    assert abs(z(10000000, "nusselt_state")) < 4.0
+    k2 = np.abs(got[10000]["ke"] - ref[10000]["ke"].mean()) < 1e-4            # Ra=1e4: steady; see the from-rest ensemble test
+    assert k2.sum() > 0.8 * k2.size and abs(got[10000]["ke"][k2].mean() / ref[10000]["ke"].mean() - 1) < 3e-6
