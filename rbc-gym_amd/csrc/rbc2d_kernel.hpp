@@ -3,19 +3,21 @@
 // One workgroup owns ONE env for a whole control interval (reference: one `step_simulation`
 // call, rbc_sim2D_api.jl:75-97, i.e. n_sub RK3 substeps x 3 stages of Oceananigans'
 // NonhydrostaticModel).  The prognostic fields u, w, b of the env (3 x NZ x NX float64 =
-// 144 KiB at 64x96) stay in the CU's 160 KiB LDS from the first stage to the last; the
-// previous-stage tendencies G^- live in registers; HBM is touched only to load the state at
-// the start and to store state + observations at the end.
+// 144 KiB at 64x96) stay in the CU's 160 KiB LDS from the first stage to the last; of the
+// previous-stage tendencies G^-, G^-_u lives in registers and G^-_b, G^-_w are parked in an
+// L2-resident global workspace; apart from that HBM is touched only to load the state at the
+// start and to store state + observations at the end.
 //
 //   thread (i, c)  i = x index (lanes run along x -> conflict-free ds_read_b64 rows)
 //                  c = z chunk of CZ=8 cells; NX*NZ/8 = 768 threads = 12 wave64 / CU
 //
 // Per stage (what Oceananigans' time_step!/update_state! do, see DESIGN.md for file map):
 //   hydrostatic-pressure column scan -> tendencies (UpwindBiased(5) advection with
-//   boundary-adjacent order reduction, ScalarDiffusivity stress divergence) -> RK3 update in
-//   registers -> divergence -> exact Poisson solve: complex FFT-96 (8x12, two rows packed per
-//   transform) along x in LDS, tridiagonal (Thomas) solve along z per wavenumber, inverse FFT
-//   -> projection.
+//   boundary-adjacent order reduction, ScalarDiffusivity stress divergence; interior waves run a
+//   copy without the wall cases) -> RK3 update in registers -> divergence -> exact Poisson solve:
+//   complex FFT-96 (8x12; row p packed with its mirror row NZ-1-p) along x in LDS, tridiagonal
+//   solve along z per wavenumber from both walls at once directly on the packed transform, inverse
+//   FFT -> projection.
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>
