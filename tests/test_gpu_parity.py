@@ -193,3 +193,46 @@ def test_masked_reset_and_nan_flag(native, ckpt_ra1e4):
     assert np.array_equal(f_before[0][0], f_after[0][0]) and np.array_equal(f_before[1][2], f_after[1][2])
     assert not sim.step(np.zeros((B, 12), np.float32))    # RBC_ERR_NAN (rbc2D.py:170-171)
     assert list(sim.get_flags()) == [0, 1, 0]
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(nz=48, heaters=8, heater_limit=0.5, obs=(6, 32), dt_solver=0.02, dt_control=0.25, ra=2e4, lz=1.5, min_b=0.5, delta_b=2.0),
+    dict(nz=32, heaters=24, heater_limit=0.9, obs=(4, 24), dt_solver=0.03, dt_control=0.2, ra=5e3, lx=3 * np.pi),
+    dict(nz=64, heaters=32, heater_limit=0.3, obs=(16, 96), dt_solver=0.025, dt_control=0.11, ra=4e4, pr=1.0),
+    dict(nz=64, heaters=1, heater_limit=0.75, obs=(2, 1), dt_solver=0.03, dt_control=0.09, ra=1e4),
+], ids=["96x48", "96x32", "96x64-32heaters", "96x64-1heater"])
+def test_non_default_configurations_match_oracle(native, oracle, cfg):
+    """Every compiled grid (96x64, 96x48, 96x32) and the run-time parameters of initialize_simulation
+    (rbc_sim2D_api.jl:17-70: Ra, Pr, domain, plate temperatures, heaters, heater_limit, sensor grid, solver / control
+    steps incl. a clipped last substep) away from the registry defaults: random reset, two actuated control intervals."""
+    cfg = dict(cfg)
+    obs = cfg.pop("obs")
+    okw = dict(cfg); nkw = dict(cfg)
+    sim = native.NativeSim(batch=2, obs_nz=obs[0], obs_nx=obs[1], random_kick=0.05, **nkw)
+    seeds = np.array([5, 6], dtype=np.uint64)
+    sim.reset(seeds)
+    orcs = []
+    for e in range(2):
+        o = oracle.OracleSim(obs=obs, kick=0.05, **okw)
+        o.reset_random(int(seeds[e]))
+        orcs.append(o)
+    b, u, w = sim.get_fields()
+    for e, o in enumerate(orcs):
+        for x, y in zip((b[e], u[e], w[e]), o.fields()):
+            assert rel_l2(x, y) < 1e-12
+    rng = np.random.default_rng(1)
+    for n in range(2):
+        act = rng.uniform(-1.5, 1.5, (2, cfg["heaters"])).astype(np.float32)      # beyond [-1, 1]: exercises the K2 rescaling
+        assert sim.step(act)
+        b, u, w = sim.get_fields()
+        nus, nuo = sim.get_nusselt()
+        ob = sim.get_obs(5)
+        for e, o in enumerate(orcs):
+            assert o.step(act[e])
+            for x, y in zip((b[e], u[e], w[e]), o.fields()):
+                assert rel_l2(x, y) < 1e-10
+            assert abs(nus[e] - o.nusselt(True)) < 1e-7 * max(1.0, abs(o.nusselt(True)))
+            assert abs(nuo[e] - o.nusselt(False)) < 1e-7 * max(1.0, abs(o.nusselt(False)))
+            assert np.allclose(ob[e][:4], o.obs_f32(5)[:4], rtol=1e-5, atol=1e-5)
+    t, s = sim.get_info()
+    assert np.allclose(t, 2 * cfg["dt_control"]) and np.all(s == 3)
