@@ -1,4 +1,5 @@
-from rbc_gym.envs.rbc2D import RayleighBenardConvection2DEnv
-from rbc_gym.envs.rbc3D import RayleighBenardConvection3DEnv
+"""Single-env classes (batch-of-one handles); the batched env lives in `rbc_gym.vector`."""
+from .rbc2D import RayleighBenardConvection2DEnv, RBCField
+from .rbc3D import RayleighBenardConvection3DEnv
 
-__all__ = ["RayleighBenardConvection2DEnv", "RayleighBenardConvection3DEnv"]
+__all__ = ["RayleighBenardConvection2DEnv", "RayleighBenardConvection3DEnv", "RBCField"]

@@ -157,13 +157,9 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
             return None
         if self.render_mode != "rgb_array":
             raise ValueError(f"the batched env renders rgb_array frames only, not {self.render_mode!r}")
-        from .envs.rbc2D import colormap
+        from .envs._common import temperature_image
         temp = self.sim.get_state(1)[:, 0]                                   # (B, nz, nx)
-        frames = []
-        for t in temp:
-            data = np.flip(np.transpose(t), axis=1)
-            frames.append(colormap(data, vmin=1, vmax=2 + self.heater_limit).transpose(1, 0, 2))
-        return tuple(frames)
+        return tuple(temperature_image(t, 1, 2 + self.heater_limit).transpose(1, 0, 2) for t in temp)
 
     def close(self, **kwargs):
         if getattr(self, "sim", None) is not None:

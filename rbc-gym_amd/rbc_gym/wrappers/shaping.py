@@ -5,7 +5,7 @@ import logging
 import numpy as np
 
 from .._gym import gym
-from ..envs.rbc2D import RBCField
+from ..envs._common import RBCField
 
 
 def find_peaks_min_height(x, height):

@@ -280,9 +280,8 @@ def test_vector_render_and_examples_run(gym, tmp_path):
     venv.close(); single.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ck = str(tmp_path / "train" / "ckpt_ra10000.h5")
-    for script, args in (("run_2D.py", ["3"]), ("run_vectorized.py", ["4", "3"]), ("timing.py", ["3"]), ("run_wrapped.py", ["3"]),
-                         ("run_checkpoint.py", [ck, "3"]), ("run_3D.py", ["2"])):
-        out = subprocess.run([sys.executable, os.path.join(root, "examples", script), *args], capture_output=True, text=True,
+    for args in (["single", "3"], ["vector", "4", "3"], ["timing", "3"], ["wrapped", "3"], ["checkpoint", ck, "3"], ["three-d", "2"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", "demo.py"), *args], capture_output=True, text=True,
                              timeout=300, env={**os.environ, "RBC_SPINUP": "3"})
         assert out.returncode == 0, out.stderr[-2000:]
 
