@@ -425,6 +425,311 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
     }
 }
 
+// ---- LDS-tiled tendency kernels ------------------------------------------------------------------------
+// A workgroup owns a (all x) x (TY rows of y) tile of one env and marches KT levels upward.  At every level the
+// horizontal planes the stencils reach (TY + 6 rows: periodic halo of 3 in y; x wraps inside the row) are staged
+// once in LDS by the whole group -- fetched into registers one level ahead so the loads fly under the arithmetic --
+// and every cross-column stencil value is an LDS read; each thread keeps its own column's z windows and the
+// carried face fluxes in registers.  Two kernels: (u, v) share the planes u, v, w(k+1); (w, b) the planes w, b.
+// About 24 global loads per cell for all four fields (marching kernels: ~90, cell-per-thread: ~380).
+#ifndef RBC_TILE_WAVES
+#define RBC_TILE_WAVES 2      // waves per SIMD the tiled kernels are compiled for (register budget 512 / waves)
+#endif
+constexpr int KT3 = 8;                 // levels per workgroup
+constexpr int TY3 = 8;                 // tile rows
+constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
+constexpr int PLANE3 = (TY3 + 6) * NXP3;
+
+struct TileGeo {
+    int nx, ny, nz, pl, rows, plane, tiles, chunks, env, j0, k0, i, jl, j, tid, nthreads;
+    __device__ __forceinline__ TileGeo(const Geo3 &g)
+    {
+        nx = g.nx; ny = g.ny; nz = g.nz; pl = nx * ny; rows = TY3 + 6; plane = rows * nx;
+        tiles = ny / TY3; chunks = nz / KT3;
+        const int blk = blockIdx.x, zc = blk % chunks, yt = (blk / chunks) % tiles;
+        env = blk / (chunks * tiles); j0 = yt * TY3; k0 = zc * KT3;
+        tid = threadIdx.x; nthreads = blockDim.x; jl = tid / nx; i = tid - jl * nx; j = j0 + jl;
+    }
+    // global offset (inside one level) of tile element idx = row * nx + column
+    __device__ __forceinline__ int src(int idx) const
+    {
+        const int r = idx / nx, c = idx - r * nx;
+        int jy = j0 - 3 + r; jy += (jy < 0) ? ny : 0; jy -= (jy >= ny) ? ny : 0;
+        return jy * nx + c;
+    }
+};
+
+template <int NPF>
+__device__ __forceinline__ void tile_fetch(const TileGeo &t, const double *lev, double (&pf)[NPF])
+{
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) { const int idx = t.tid + q * t.nthreads; pf[q] = (idx < t.plane) ? lev[t.src(idx)] : 0.0; }
+}
+template <int NPF>
+__device__ __forceinline__ void tile_store(const TileGeo &t, double *dst, const double (&pf)[NPF])
+{
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int idx = t.tid + q * t.nthreads;
+        if (idx < t.plane) { const int r = idx / t.nx, c = idx - r * t.nx; dst[r * NXP3 + c] = pf[q]; }
+    }
+}
+
+// (u, v): launch with blockDim = nx * TY3, grid = B * (ny/TY3) * (nz/KT3), LDS = 3 planes
+template <int NPF>
+__global__ void __launch_bounds__(512, RBC_TILE_WAVES) k3_tile_uv(Geo3 g, const double *cur, double *nxt, double *gm, const double *phy,
+                                                  const double *nu_kappa, double dt, double gam, double zet)
+{
+    extern __shared__ __attribute__((aligned(16))) double tile_sm[];
+    const TileGeo t(g);
+    const int nx = t.nx, nz = t.nz, pl = t.pl;
+    double *PU = tile_sm, *PV = tile_sm + PLANE3, *PW = tile_sm + 2 * PLANE3;        // u(k), v(k), w(k+1)
+    constexpr int IU = 0, IV = PLANE3, IW = 2 * PLANE3;
+    const double *sb = cur + (size_t)t.env * g.env_stride;
+    const double *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double *ph = phy + (size_t)t.env * g.nc;
+    const double nu = nu_kappa[2 * t.env];
+    const double rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
+    int xi[7];
+    wrap7(t.i, nx, xi);
+    const int col = t.j * nx + t.i;                               // own column inside a level
+    const int jm = (t.j == 0) ? t.ny - 1 : t.j - 1;
+    // one LDS address per x offset; the plane and the y offset are immediates of the ds_read
+    const double *xb[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) xb[a] = tile_sm + (t.jl + 3) * NXP3 + xi[a];
+    auto L = [&](int P, int a, int b) -> double { return xb[a + 3][P + b * NXP3]; };
+    auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
+    auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
+    auto own = [&](const double *f, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + col]; };
+
+    // stage level k0 (u, v) and k0+1 (w; level k0 itself is only needed for the chunk's bottom face, read below)
+    double pfu[NPF], pfv[NPF], pfw[NPF];
+    tile_fetch(t, u + (size_t)t.k0 * pl, pfu); tile_fetch(t, v + (size_t)t.k0 * pl, pfv);
+    tile_fetch(t, w + (size_t)t.k0 * pl, pfw);
+    tile_store(t, PW, pfw);                                       // w(k0) first: bottom-face terms of the chunk
+    __syncthreads();
+    double winu[6], winv[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { winu[q] = own(u, t.k0 - 3 + q); winv[q] = own(v, t.k0 - 3 + q); }
+    double fbu = 0.0, dwbu = 0.0, fdnu, fbv = 0.0, dwbv = 0.0, fdnv;
+    if (t.k0 > 0) {
+        const double wc = L(IW, 0, 0), wmx = L(IW, -1, 0), wmy = L(IW, 0, -1);
+        fbu = upw(sym4(L(IW, -2, 0), wmx, wc, L(IW, 1, 0)), zfL(winu, t.k0, nz), zfR(winu, t.k0, nz));
+        fbv = upw(sym4(L(IW, 0, -2), wmy, wc, L(IW, 0, 1)), zfL(winv, t.k0, nz), zfR(winv, t.k0, nz));
+        dwbu = wc - wmx; dwbv = wc - wmy;
+        fdnu = winu[2]; fdnv = winv[2];
+    } else { fdnu = ghost_lo(winu[3], 0.0); fdnv = ghost_lo(winv[3], 0.0); }
+    __syncthreads();
+    tile_store(t, PU, pfu); tile_store(t, PV, pfv);
+    tile_fetch(t, w + (size_t)min(t.k0 + 1, nz) * pl, pfw);
+    tile_store(t, PW, pfw);
+    __syncthreads();
+
+    const size_t eb = (size_t)t.env * g.env_stride;
+    // per-level global operands of this thread travel one level ahead of their use, like the planes
+    double nu5 = own(u, t.k0 + 3), nv5 = own(v, t.k0 + 3);
+    double np0 = ph[(size_t)t.k0 * pl + col], npx = ph[(size_t)t.k0 * pl + t.j * nx + xi[2]], npy = ph[(size_t)t.k0 * pl + jm * nx + t.i];
+    double ngu = gm[eb + g.nc + (size_t)t.k0 * pl + col], ngv = gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col];
+    for (int k = t.k0; k < t.k0 + KT3; ++k) {
+        const bool more = (k + 1 < t.k0 + KT3);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { winu[q] = winu[q + 1]; winv[q] = winv[q + 1]; }
+        winu[5] = nu5; winv[5] = nv5;
+        const double p0 = np0, pxm = npx, pym = npy, gpu_ = ngu, gpv_ = ngv;
+        if (more) {                                               // next level's planes and operands fly under this level's arithmetic
+            tile_fetch(t, u + (size_t)(k + 1) * pl, pfu); tile_fetch(t, v + (size_t)(k + 1) * pl, pfv);
+            tile_fetch(t, w + (size_t)min(k + 2, nz) * pl, pfw);
+            nu5 = own(u, k + 4); nv5 = own(v, k + 4);
+            np0 = ph[(size_t)(k + 1) * pl + col]; npx = ph[(size_t)(k + 1) * pl + t.j * nx + xi[2]]; npy = ph[(size_t)(k + 1) * pl + jm * nx + t.i];
+            ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col];
+        }
+        const bool top = (k + 1 >= nz);
+        const double wc = top ? 0.0 : L(IW, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- u at (x-face i, j, k): `a` along x, `b` along y ----
+        {
+            const double f0 = winu[2];
+            double q7[7], c7[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IU, q - 3, 0); c7[q] = (q == 3) ? f0 : L(IU, 0, q - 3); }
+            const double fe = upw(sym4(q7[2], q7[3], q7[4], q7[5]), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const double fw = upw(sym4(q7[1], q7[2], q7[3], q7[4]), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const double on_m = L(IV, -1, 1), on_c = L(IV, 0, 1), os_m = L(IV, -1, 0), os_c = winv[2];
+            const double fn = upw(sym4(L(IV, -2, 1), on_m, on_c, L(IV, 1, 1)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+            const double fs = upw(sym4(L(IV, -2, 0), os_m, os_c, L(IV, 1, 0)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            double ft = 0.0, dwt = 0.0, fup;
+            if (!top) {
+                const double wm = L(IW, -1, 0);
+                ft = upw(sym4(L(IW, -2, 0), wm, wc, L(IW, 1, 0)), zfL(winu, k + 1, nz), zfR(winu, k + 1, nz));
+                dwt = wc - wm; fup = winu[3];
+            } else fup = ghost_hi(f0, 0.0);
+            const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbu) * rdz;
+            const double vis = nu * (2.0 * ((q7[4] - f0) - (f0 - q7[2])) * rdx * rdx
+                                     + (((c7[4] - f0) * rdy + (on_c - on_m) * rdx) - ((f0 - c7[2]) * rdy + (os_c - os_m) * rdx)) * rdy
+                                     + (((fup - f0) * rdz + dwt * rdx) - ((f0 - fdnu) * rdz + dwbu * rdx)) * rdz);
+            const double G = vis - adv - (p0 - pxm) * rdx;
+            const size_t o = eb + g.nc + (size_t)k * pl + col;
+            nxt[o] = f0 + dt * (gam * G + zet * gpu_);
+            gm[o] = G;
+            fbu = ft; dwbu = dwt; fdnu = f0;
+        }
+        __builtin_amdgcn_sched_barrier(0);           // keep the two sections' live ranges apart
+        // ---- v at (i, y-face j, k): the mirror image, `a` along y, `b` along x ----
+        {
+            const double f0 = winv[2];
+            double q7[7], c7[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IV, 0, q - 3); c7[q] = (q == 3) ? f0 : L(IV, q - 3, 0); }
+            const double fe = upw(sym4(q7[2], q7[3], q7[4], q7[5]), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const double fw = upw(sym4(q7[1], q7[2], q7[3], q7[4]), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const double on_m = L(IU, 1, -1), on_c = L(IU, 1, 0), os_m = L(IU, 0, -1), os_c = winu[2];
+            const double fn = upw(sym4(L(IU, 1, -2), on_m, on_c, L(IU, 1, 1)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+            const double fs = upw(sym4(L(IU, 0, -2), os_m, os_c, L(IU, 0, 1)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            double ft = 0.0, dwt = 0.0, fup;
+            if (!top) {
+                const double wm = L(IW, 0, -1);
+                ft = upw(sym4(L(IW, 0, -2), wm, wc, L(IW, 0, 1)), zfL(winv, k + 1, nz), zfR(winv, k + 1, nz));
+                dwt = wc - wm; fup = winv[3];
+            } else fup = ghost_hi(f0, 0.0);
+            const double adv = (fe - fw) * rdy + (fn - fs) * rdx + (ft - fbv) * rdz;
+            const double vis = nu * (2.0 * ((q7[4] - f0) - (f0 - q7[2])) * rdy * rdy
+                                     + (((c7[4] - f0) * rdx + (on_c - on_m) * rdy) - ((f0 - c7[2]) * rdx + (os_c - os_m) * rdy)) * rdx
+                                     + (((fup - f0) * rdz + dwt * rdy) - ((f0 - fdnv) * rdz + dwbv * rdy)) * rdz);
+            const double G = vis - adv - (p0 - pym) * rdy;
+            const size_t o = eb + 2 * (size_t)g.nc + (size_t)k * pl + col;
+            nxt[o] = f0 + dt * (gam * G + zet * gpv_);
+            gm[o] = G;
+            fbv = ft; dwbv = dwt; fdnv = f0;
+        }
+        if (more) {
+            __syncthreads();                                      // every read of this level's planes is done
+            tile_store(t, PU, pfu); tile_store(t, PV, pfv); tile_store(t, PW, pfw);
+            __syncthreads();
+        }
+    }
+}
+
+// (w, b): same launch shape, LDS = 2 planes (w and b at the current level)
+template <int NPF>
+__global__ void __launch_bounds__(512, RBC_TILE_WAVES) k3_tile_wb(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
+                                                  const double *nu_kappa, double dt, double gam, double zet)
+{
+    extern __shared__ __attribute__((aligned(16))) double tile_sm[];
+    const TileGeo t(g);
+    const int nx = t.nx, nz = t.nz, pl = t.pl;
+    double *PW = tile_sm, *PB = tile_sm + PLANE3;
+    constexpr int IW = 0, IB = PLANE3;
+    const double *sb = cur + (size_t)t.env * g.env_stride;
+    const double *b = sb, *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double nu = nu_kappa[2 * t.env], ka = nu_kappa[2 * t.env + 1];
+    const double rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
+    int xi[7];
+    wrap7(t.i, nx, xi);
+    const int col = t.j * nx + t.i;
+    const int colE = t.j * nx + xi[4];                            // column (i+1, j)
+    const int colN = ((t.j + 1 == t.ny) ? 0 : t.j + 1) * nx + t.i;   // column (i, j+1)
+    const double *xb[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) xb[a] = tile_sm + (t.jl + 3) * NXP3 + xi[a];
+    auto L = [&](int P, int a, int bb) -> double { return xb[a + 3][P + bb * NXP3]; };
+    auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
+    auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
+    auto cen = [&](const double *f, int c, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + c]; };
+    auto fac = [&](int kk) -> double { return w[(size_t)min(max(kk, 0), nz) * pl + col]; };
+
+    double pfw[NPF], pfb[NPF];
+    tile_fetch(t, w + (size_t)t.k0 * pl, pfw); tile_fetch(t, b + (size_t)t.k0 * pl, pfb);
+    double winw[6], winb[6], au[6], eu[6], av[6], ev[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        winw[q] = fac(t.k0 - 3 + q); winb[q] = cen(b, col, t.k0 - 3 + q);
+        au[q] = cen(u, col, t.k0 - 4 + q); eu[q] = cen(u, colE, t.k0 - 4 + q);
+        av[q] = cen(v, col, t.k0 - 4 + q); ev[q] = cen(v, colN, t.k0 - 4 + q);
+    }
+    double fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : 0.0;
+    double fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : 0.0;
+    double bdn = (t.k0 > 0) ? winb[2] : ghost_lo(winb[3], bottom_T(g, actT + (size_t)t.env * g.heaters * g.heaters, t.i, t.j));
+    tile_store(t, PW, pfw); tile_store(t, PB, pfb);
+    __syncthreads();
+
+    const size_t eb = (size_t)t.env * g.env_stride;
+    // per-level global operands of this thread travel one level ahead of their use, like the planes
+    double nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
+    double nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = cen(v, col, t.k0 + 2), nev = cen(v, colN, t.k0 + 2);
+    double ngw = gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col], ngb = gm[eb + (size_t)t.k0 * pl + col];
+    for (int k = t.k0; k < t.k0 + KT3; ++k) {
+        const bool more = (k + 1 < t.k0 + KT3);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            winw[q] = winw[q + 1]; winb[q] = winb[q + 1];
+            au[q] = au[q + 1]; eu[q] = eu[q + 1]; av[q] = av[q + 1]; ev[q] = ev[q + 1];
+        }
+        winw[5] = nw5; winb[5] = nb5;                             // w faces k-2..k+3, b centres k-2..k+3
+        au[5] = nau; eu[5] = neu; av[5] = nav; ev[5] = nev;       // u, v levels k-3..k+2
+        const double gpw_ = ngw, gpb_ = ngb;
+        if (more) {
+            tile_fetch(t, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, b + (size_t)(k + 1) * pl, pfb);
+            nw5 = fac(k + 4); nb5 = cen(b, col, k + 4);
+            nau = cen(u, col, k + 3); neu = cen(u, colE, k + 3); nav = cen(v, col, k + 3); nev = cen(v, colN, k + 3);
+            ngw = gm[eb + 3 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; ngb = gm[eb + (size_t)(k + 1) * pl + col];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- w at (i, j, z-face k); the wall face k = 0 never evolves ----
+        {
+            const double w0 = winw[2];
+            const double ft = upw(zcS(winw, k, nz), zcL(winw, k, nz), zcR(winw, k, nz));
+            const size_t o = eb + 3 * (size_t)g.nc + (size_t)k * pl + col;
+            if (k > 0) {
+                double q7[7], c7[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : L(IW, q - 3, 0); c7[q] = (q == 3) ? w0 : L(IW, 0, q - 3); }
+                const double fe = upw(zfS(eu, k, nz), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+                const double fw = upw(zfS(au, k, nz), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+                const double fn = upw(zfS(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+                const double fs = upw(zfS(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbw) * rdz;
+                const double vis = nu * ((((eu[3] - eu[2]) * rdz + (q7[4] - w0) * rdx) - ((au[3] - au[2]) * rdz + (w0 - q7[2]) * rdx)) * rdx
+                                         + (((ev[3] - ev[2]) * rdz + (c7[4] - w0) * rdy) - ((av[3] - av[2]) * rdz + (w0 - c7[2]) * rdy)) * rdy
+                                         + 2.0 * ((winw[3] - w0) - (w0 - winw[1])) * rdz * rdz);
+                const double G = vis - adv;
+                nxt[o] = w0 + dt * (gam * G + zet * gpw_);
+                gm[o] = G;
+            } else { nxt[o] = 0.0; gm[o] = 0.0; }
+            fbw = ft;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- b at the centre (i, j, k) ----
+        {
+            const double b0 = winb[2];
+            double q7[7], c7[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : L(IB, q - 3, 0); c7[q] = (q == 3) ? b0 : L(IB, 0, q - 3); }
+            const double fe = upw(eu[3], left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const double fw = upw(au[3], left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const double fn = upw(ev[3], left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+            const double fs = upw(av[3], left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            double ft = 0.0, bup;
+            if (k + 1 < nz) { ft = upw(winw[3], zfL(winb, k + 1, nz), zfR(winb, k + 1, nz)); bup = winb[3]; }
+            else bup = ghost_hi(b0, g.min_b);
+            const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbb) * rdz;
+            const double dif = ka * (((q7[4] - b0) - (b0 - q7[2])) * rdx * rdx + ((c7[4] - b0) - (b0 - c7[2])) * rdy * rdy
+                                     + ((bup - b0) - (b0 - bdn)) * rdz * rdz);
+            const double G = dif - adv;
+            const size_t o = eb + (size_t)k * pl + col;
+            nxt[o] = b0 + dt * (gam * G + zet * gpb_);
+            gm[o] = G;
+            fbb = ft; bdn = b0;
+        }
+        if (more) {
+            __syncthreads();
+            tile_store(t, PW, pfw); tile_store(t, PB, pfb);
+            __syncthreads();
+        }
+    }
+    if (t.k0 + KT3 == nz) nxt[eb + 3 * (size_t)g.nc + (size_t)nz * pl + col] = 0.0;      // top wall face
+}
+
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------
 // data: [rows][n] complex (re,im interleaved), n = n1*n2, line stride `ls`, element stride `es`
 // (so the same routine does rows and columns).  out-of-place src -> dst.  sign=-1 forward, +1 inverse.

@@ -167,20 +167,24 @@ def test_flowstats_pin_p4(native):
 
 
 def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch):
-    """The z-marching tendency kernels (nz % 4 == 0) and the cell-per-thread ones (any nz; RBC_NO_MARCH=1)
-    evaluate the same expressions; a grid with nz = 10 takes the generic path and is checked against the oracle."""
+    """The LDS-tiled tendency kernels (nz % 8 == 0, ny % 8 == 0), the z-marching ones (nz % 4 == 0; RBC_NO_TILE=1) and
+    the cell-per-thread ones (any grid; RBC_NO_MARCH=1) evaluate the same expressions; a grid with nz = 10 takes the
+    generic path and is checked against the oracle."""
     ic = _developed_state(o3, 5)
     act = np.random.default_rng(6).uniform(-1, 1, (1, 8, 8)).astype(np.float32)
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RBC_NO_MARCH", flag)
+    for no_tile, no_march in (("0", "0"), ("1", "0"), ("1", "1")):          # LDS-tiled / z-marching / cell-per-thread
+        monkeypatch.setenv("RBC_NO_TILE", no_tile)
+        monkeypatch.setenv("RBC_NO_MARCH", no_march)
         sim = native.NativeSim3D(batch=1, shape=SHAPE, domain=DOMAIN, ra=5000.0, dt_control=0.03, dt_solver=0.01)
         sim.reset_from_arrays(*[x[None] for x in ic])
         assert sim.step(act)
         outs.append(sim.get_fields())
         sim.close()
-    for x, y in zip(*outs):
-        assert rel_l2(x, y) < 1e-13
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert rel_l2(x, y) < 1e-13
+    monkeypatch.delenv("RBC_NO_TILE")
     monkeypatch.delenv("RBC_NO_MARCH")
     shape = (10, 24, 32)
     o = o3.Oracle3D(ra=5000.0, shape=shape, domain=DOMAIN, kick=0.2, dt_control=0.03, dt_solver=0.01)
