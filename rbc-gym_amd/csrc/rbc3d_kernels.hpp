@@ -1,11 +1,11 @@
-// rbc3d_kernels.hpp -- streaming 3D Boussinesq integrator for gfx950 (first, correctness-first cut).
+// rbc3d_kernels.hpp -- streaming 3D Boussinesq integrator for gfx950.
 //
 // Replaces `step_simulation`/`initialize_simulation` of src/rbc_gym/sim/rbc_sim3D_api.jl (77-101,
 // 17-72) for a batch of envs.  A 3D env (32x48x48: 2.4 MB of fp64 state) does not fit one CU's LDS,
 // so unlike the 2D kernel the state lives in HBM/L2 (32 envs = 75 MB, resident in the 256 MB
 // Infinity Cache) and every RK3 stage is a short sequence of launches:
-//   hydrostatic scan -> 4 tendency kernels (one thread per cell, plain cached loads) writing U* into
-//   the other state buffer -> per-z-slab 2D FFT in LDS -> per-(kx,ky) tridiagonal sweep -> inverse
+//   hydrostatic scan -> tendency kernels (LDS-tiled; z-marching and cell-per-thread fallbacks) writing U*
+//   into the other state buffer -> per-z-slab 2D FFT in LDS -> per-(kx,ky) tridiagonal sweep -> inverse
 //   FFT -> projection.
 // Same discretisation as the 2D kernel; layouts [k][j][i].
 #pragma once
