@@ -10,6 +10,7 @@ struct rbc3_state {
     double *st[2] = {nullptr, nullptr};   // ping-pong state buffers [B][b|u|v|w]
     int cur = 0;
     double *gm = nullptr, *phy = nullptr, *phi = nullptr, *tab = nullptr, *actT = nullptr, *dbg = nullptr;
+    double2 *jct = nullptr;            // junction values of the packed z solve, [env][mode]
     double2 *spec = nullptr;
     size_t fft_lds = 0;
     double tff = 1.0;
@@ -64,6 +65,7 @@ int create3d(rbc_handle *h)
     HIP3(hipMalloc(&s->phy, B * (size_t)g.nc * sizeof(double)));
     HIP3(hipMalloc(&s->phi, B * (size_t)g.nc * sizeof(double)));
     HIP3(hipMalloc(&s->spec, B * (size_t)g.nc * sizeof(double2)));
+    HIP3(hipMalloc(&s->jct, B * (size_t)g.nx * g.ny * sizeof(double2)));
     HIP3(hipMalloc(&s->actT, B * (size_t)c.heaters * c.heaters * sizeof(double)));
     HIP3(hipMemset(s->actT, 0, B * (size_t)c.heaters * c.heaters * sizeof(double)));
     {   // pivots of the z operator for every horizontal mode: tab[k][n][m] = 1/piv_k
@@ -86,6 +88,8 @@ int create3d(rbc_handle *h)
     }
     HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
     HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_ifft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
+    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
+    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_ifft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
     return RBC_OK;
 }
 
@@ -95,7 +99,7 @@ void destroy3d(rbc_handle *h)
     if (!s) return;
     for (auto &g : s->gexec)
         if (g) (void)hipGraphExecDestroy(g);
-    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->actT, s->tab, s->dbg};
+    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->actT, s->tab, s->dbg};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -110,9 +114,17 @@ int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
     rbc3_state *s = h->s3;
     const rbc3::Geo3 &g = s->g;
     const int B = h->B;
-    hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
-    hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, s->spec, s->tab, B);
-    hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
+    if (g.nz % 2 == 0 && !h->no_pair) {      // mirror slabs packed as one complex transform, z solve on the packed spectrum
+        const dim3 gm_ = grid_for((size_t)B * g.nx * g.ny, 128);
+        hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
+        hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
+        hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
+        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
+    } else {
+        hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
+        hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, s->spec, s->tab, B);
+        hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
+    }
     hipLaunchKernelGGL(rbc3::k3_correct, grid_for((size_t)B * g.nc, 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
     HIP3(hipGetLastError());
     return RBC_OK;

@@ -959,6 +959,131 @@ __global__ void k3_ifft(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx].x * sc;
 }
 
+
+// ---- mirror-slab packing (even nz) ----------------------------------------------------------------------
+// Slab k (real part) and its mirror image nz-1-k (imaginary part) go through ONE complex 2D FFT, and the packed
+// spectrum is never unpacked: the z operator is real and mirror symmetric, so eliminating from both walls applies,
+// at step k, the same real recurrence to slab k (upward) and slab nz-1-k (downward), i.e. to the real and the
+// imaginary part of the packed value alike ("Poisson", has the argument).  Only the 2x2
+// junction between slabs nz/2-1 and nz/2 mixes the two sweeps, through the packed value of the conjugate mode
+// (-kx, -ky):  X = jf (P - i c conj(P')).  Half the FFTs, half the spectrum, sweeps of half the length.
+__global__ void k3_rhs_fft_pair(Geo3 g, FftPlan pl, const double *st, double2 *spec, double dts)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2;
+    const int env = blockIdx.x / half, k = blockIdx.x - env * half, km = nz - 1 - k;
+    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    const double *sb = st + (size_t)env * g.env_stride;
+    const double *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double rdt = 1.0 / dts;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) {
+        const int j = idx / nx, i = idx - j * nx;
+        const int ip = (i + 1 == nx) ? 0 : i + 1, jp = (j + 1 == ny) ? 0 : j + 1;
+        const int e = j * nx + ip, n = jp * nx + i;
+        auto div = [&](int kk) -> double {
+            const size_t c = (size_t)kk * pln;
+            const double wt = (kk + 1 < nz) ? w[c + pln + idx] : 0.0;
+            const double wb = (kk > 0) ? w[c + idx] : 0.0;
+            return (u[c + e] - u[c + idx]) * g.rdx + (v[c + n] - v[c + idx]) * g.rdy + (wt - wb) * g.rdz;
+        };
+        A[idx] = make_double2(div(k) * rdt, div(km) * rdt);
+    }
+    __syncthreads();
+    slab_fft2d(A, T, nx, ny, pl, twx, twy, -1);
+    double2 *o = spec + ((size_t)env * half + k) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx];
+}
+
+// forward elimination of the packed spectrum over k = 0..nz/2-1; the junction value also goes to jct[env][mode]
+__global__ void k3_thomas_pair_fwd(Geo3 g, double2 *spec, double2 *jct, const double *tab, int B)
+{
+    const int pln = g.nx * g.ny, half = g.nz / 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pln * B) return;
+    const int env = t / pln, mn = t - env * pln;
+    double2 *s = spec + (size_t)env * half * pln + mn;
+    const double o = g.rdz * g.rdz;
+    constexpr int BK = 8;
+    double yr = 0.0, yi = 0.0;
+    int k = 0;
+    for (; k + BK <= half; k += BK) {
+        double inv[BK]; double2 r[BK];
+#pragma unroll
+        for (int q = 0; q < BK; ++q) { inv[q] = tab[(size_t)(k + q) * pln + mn]; r[q] = s[(size_t)(k + q) * pln]; }
+#pragma unroll
+        for (int q = 0; q < BK; ++q) {
+            yr = r[q].x * inv[q] - (inv[q] * o) * yr;
+            yi = r[q].y * inv[q] - (inv[q] * o) * yi;
+            s[(size_t)(k + q) * pln] = make_double2(yr, yi);
+        }
+    }
+    for (; k < half; ++k) {
+        const double inv = tab[(size_t)k * pln + mn];
+        const double2 r = s[(size_t)k * pln];
+        yr = r.x * inv - (inv * o) * yr;
+        yi = r.y * inv - (inv * o) * yi;
+        s[(size_t)k * pln] = make_double2(yr, yi);
+    }
+    jct[(size_t)env * pln + mn] = make_double2(yr, yi);
+}
+
+// junction with the conjugate mode, then back-substitution outward
+__global__ void k3_thomas_pair_bwd(Geo3 g, double2 *spec, const double2 *jct, const double *tab, int B)
+{
+    const int nx = g.nx, ny = g.ny, pln = nx * ny, half = g.nz / 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pln * B) return;
+    const int env = t / pln, mn = t - env * pln;
+    const int n = mn / nx, m = mn - n * nx;
+    const int mp = ((n == 0) ? 0 : ny - n) * nx + ((m == 0) ? 0 : nx - m);     // mode (-kx, -ky)
+    double2 *s = spec + (size_t)env * half * pln + mn;
+    const double o = g.rdz * g.rdz;
+    const double2 P = jct[(size_t)env * pln + mn], Pc = jct[(size_t)env * pln + mp];
+    const double c = tab[(size_t)(half - 1) * pln + mn] * o;
+    double xr, xi;
+    if (mn == 0) { xr = P.x; xi = 0.0; }                                        // singular mean mode: pin phi = 0 in slab nz/2
+    else { const double jf = 1.0 / (1.0 - c * c); xr = jf * (P.x - c * Pc.y); xi = jf * (P.y - c * Pc.x); }
+    s[(size_t)(half - 1) * pln] = make_double2(xr, xi);
+    constexpr int BK = 8;
+    int k = half - 2;
+    for (; k - BK + 1 >= 0; k -= BK) {
+        double cp[BK]; double2 y[BK];
+#pragma unroll
+        for (int q = 0; q < BK; ++q) { cp[q] = tab[(size_t)(k - q) * pln + mn] * o; y[q] = s[(size_t)(k - q) * pln]; }
+#pragma unroll
+        for (int q = 0; q < BK; ++q) {
+            xr = y[q].x - cp[q] * xr; xi = y[q].y - cp[q] * xi;
+            s[(size_t)(k - q) * pln] = make_double2(xr, xi);
+        }
+    }
+    for (; k >= 0; --k) {
+        const double cp = tab[(size_t)k * pln + mn] * o;
+        const double2 y = s[(size_t)k * pln];
+        xr = y.x - cp * xr; xi = y.y - cp * xi;
+        s[(size_t)k * pln] = make_double2(xr, xi);
+    }
+}
+
+// inverse 2D FFT of a packed slab pair -> phi of slab k (real part) and of slab nz-1-k (imaginary part)
+__global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2;
+    const int env = blockIdx.x / half, k = blockIdx.x - env * half;
+    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    const double2 *in = spec + ((size_t)env * half + k) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) A[idx] = in[idx];
+    __syncthreads();
+    slab_fft2d(A, T, nx, ny, pl, twx, twy, +1);
+    const double sc = 1.0 / (double)pln;
+    double *lo = phi + ((size_t)env * nz + k) * pln, *hi = phi + ((size_t)env * nz + (nz - 1 - k)) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { lo[idx] = A[idx].x * sc; hi[idx] = A[idx].y * sc; }
+}
+
 // pressure_correct_velocities!
 __global__ void k3_correct(Geo3 g, double *st, const double *phi, double dts, int B, const uint8_t *mask)
 {

@@ -42,6 +42,7 @@ struct rbc_handle {
     rbc3_state *s3 = nullptr;          // non-null for dim == 3 (rbc3d_host.hpp)
     int obs_norm = 0, obs_clip = 0;    // rbc_set_obs_normalization
     float obs_min[5] = {0, 0, 0, 0, 0}, obs_rng[5] = {1, 1, 1, 1, 1}, obs_maxval = 1.0f;
+    bool no_pair = false;              // RBC_NO_PAIR=1: unpacked 3D Poisson path (one FFT per slab; A/B and odd nz)
     bool no_tile = false;              // RBC_NO_TILE=1: skip the LDS-tiled 3D tendency kernels (A/B and debug)
     bool no_march = false;             // RBC_NO_MARCH=1: use the cell-per-thread 3D tendency kernels (A/B and debug)
     bool no_graph = true;              // RBC_USE_GRAPH=1 replays the 3D env-step as a captured HIP graph (measured: +1 %, so off by default)
@@ -217,6 +218,7 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     { const char *e = std::getenv("RBC_USE_GRAPH"); h->no_graph = !(e && e[0] == '1'); }
     { const char *e = std::getenv("RBC_NO_MARCH"); h->no_march = e && e[0] == '1'; }
     { const char *e = std::getenv("RBC_NO_TILE"); h->no_tile = e && e[0] == '1'; }
+    { const char *e = std::getenv("RBC_NO_PAIR"); h->no_pair = e && e[0] == '1'; }
     if (cfg->dim == 3) { /* streaming kernels, any grid whose horizontal slab fits the LDS FFT */ }
     else if (cfg->nx == 96 && cfg->nz == 64) bind_kernel<96, 64>(h);
     else if (cfg->nx == 96 && cfg->nz == 48) bind_kernel<96, 48>(h);

@@ -173,9 +173,11 @@ def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch):
     ic = _developed_state(o3, 5)
     act = np.random.default_rng(6).uniform(-1, 1, (1, 8, 8)).astype(np.float32)
     outs = []
-    for no_tile, no_march in (("0", "0"), ("1", "0"), ("1", "1")):          # LDS-tiled / z-marching / cell-per-thread
+    # LDS-tiled / z-marching / cell-per-thread tendencies; last: the unpacked Poisson path (one FFT per slab)
+    for no_tile, no_march, no_pair in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("0", "0", "1")):
         monkeypatch.setenv("RBC_NO_TILE", no_tile)
         monkeypatch.setenv("RBC_NO_MARCH", no_march)
+        monkeypatch.setenv("RBC_NO_PAIR", no_pair)
         sim = native.NativeSim3D(batch=1, shape=SHAPE, domain=DOMAIN, ra=5000.0, dt_control=0.03, dt_solver=0.01)
         sim.reset_from_arrays(*[x[None] for x in ic])
         assert sim.step(act)
@@ -183,8 +185,9 @@ def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch):
         sim.close()
     for other in outs[1:]:
         for x, y in zip(outs[0], other):
-            assert rel_l2(x, y) < 1e-13
+            assert rel_l2(x, y) < 1e-12
     monkeypatch.delenv("RBC_NO_TILE")
+    monkeypatch.delenv("RBC_NO_PAIR")
     monkeypatch.delenv("RBC_NO_MARCH")
     shape = (10, 24, 32)
     o = o3.Oracle3D(ra=5000.0, shape=shape, domain=DOMAIN, kick=0.2, dt_control=0.03, dt_solver=0.01)
