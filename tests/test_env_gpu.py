@@ -219,16 +219,17 @@ def test_3d_env_contract(gym, tmp_path):
         env.step(np.zeros((4, 4), np.float32))
     o1, _ = env.reset(seed=4); o2, _ = env.reset()
     assert np.array_equal(o1, o2)
-    # checkpoint path (npz container with v): the chosen episode comes back as the state
-    from rbc_gym.checkpoint import write_checkpoint_npz
+    # checkpoint path (HDF5 in the reference's layout, and the npz container): the chosen episode comes back as the state
+    from rbc_gym.checkpoint import write_checkpoint
     f = env.unwrapped.sim.get_fields()
-    ck = str(tmp_path / "c3.npz")
-    write_checkpoint_npz(ck, f[0], f[1], f[3], v=f[2])
     env.close()
-    env2 = gym.make(ID3, state_shape=(8, 16, 16), checkpoint=ck, checkpoint_idx=0)
-    o3, _ = env2.reset(seed=1)
-    assert np.array_equal(o3[0], f[0][0].astype(np.float32))
-    env2.close()
+    for name in ("3D_ckpt_ra2500.h5", "c3.npz"):
+        ck = str(tmp_path / name)
+        write_checkpoint(ck, f[0], f[1], f[3], v=f[2], start_seed=9)
+        env2 = gym.make(ID3, state_shape=(8, 16, 16), checkpoint=ck, checkpoint_idx=0)
+        o3, _ = env2.reset(seed=1)
+        assert np.array_equal(o3[0], f[0][0].astype(np.float32)) and np.array_equal(o3[2], f[2][0].astype(np.float32))
+        env2.close()
 
 
 def test_fused_observation_normalisation_is_bit_identical_to_the_numpy_wrapper(gym):
