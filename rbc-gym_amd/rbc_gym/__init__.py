@@ -1,5 +1,5 @@
 """rbc_gym on the MI355X-native stepper.  Importing the package registers the reference's two env ids with the
-reference's default kwargs (src/rbc_gym/__init__.py:4-38); the 2D id additionally gets a vector entry point, so
+reference's default kwargs (src/rbc_gym/__init__.py:4-38); both ids additionally get a vector entry point, so
 `gym.make_vec` returns the device-batched env instead of one process per env."""
 from math import pi
 
@@ -16,6 +16,7 @@ ENV_SPECS = {
     },
     "rbc_gym/RayleighBenardConvection3D-v0": {
         "entry_point": "rbc_gym.envs:RayleighBenardConvection3DEnv",
+        "vector_entry_point": "rbc_gym.vector:RayleighBenardConvection3DVectorEnv",
         "kwargs": dict(_COMMON, rayleigh_number=500, prandtl_number=0.7, domain=[2, 4 * pi, 4 * pi], state_shape=(16, 32, 32),
                        temperature_difference=[1, 2], heater_segments=8, heater_limit=0.9, heater_duration=0.125),
     },

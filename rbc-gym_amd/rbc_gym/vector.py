@@ -34,46 +34,25 @@ def _batch_space(space, n):
                           shape=(n,) + space.shape, dtype=space.dtype)
 
 
-class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
-    metadata = {"render_modes": ["rgb_array"], "render_fps": 10, "autoreset_mode": "NextStep"}
+class _BatchedEnv(gym.vector.VectorEnv):
+    """Seeding, NEXT_STEP autoreset and info stacking shared by the batched 2D and 3D envs.  Subclasses set
+    `self.sim`, the spaces, `_fields` (checkpoint datasets) and implement `_observations()` / `_stacked_info()`."""
 
-    def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
-                 state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
-                 use_gpu=True, checkpoint=None, render_mode=None, device=0, info_state=True, **_ignored):
-        self.num_envs = int(num_envs)
-        self.ra = rayleigh_number
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 10, "autoreset_mode": "NextStep"}
+    _fields = ("b", "u", "w")
+
+    def _finish_init(self, num_envs, episode_length, checkpoint, render_mode):
         self.episode_length = episode_length
-        self.observation_shape = list(observation_shape)
-        self.state_shape = list(state_shape)
-        self.temperature_difference = [1, 2]
-        self.heater_segments = heater_segments
-        self.heater_limit = heater_limit
-        self.heater_duration = heater_duration
-        self.include_pressure = pressure
-        self.episode_steps = int(episode_length / heater_duration)
         self.checkpoint = checkpoint
         self.render_mode = render_mode
-        self.info_state = info_state
         self.logger = logging.getLogger(__name__)
-
-        self.single_action_space, self.single_observation_space = build_spaces(self.observation_shape, heater_segments,
-                                                                               heater_limit, pressure)
-        self.action_space = _batch_space(self.single_action_space, self.num_envs)
-        self.observation_space = _batch_space(self.single_observation_space, self.num_envs)
-
-        ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
-        self.sim = _native.NativeSim(batch=self.num_envs, device=device,
-                                     **sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments,
-                                                  heater_limit, heater_duration))
-        if np.ndim(rayleigh_number) > 0:                 # per-env Rayleigh numbers (Ra sweeps)
-            self.sim.set_rayleigh(np.asarray(rayleigh_number, dtype=np.float64))
-        self._nch = 5 if pressure else 3
+        self.action_space = _batch_space(self.single_action_space, num_envs)
+        self.observation_space = _batch_space(self.single_observation_space, num_envs)
         self._seeds = None
-        self._autoreset = np.zeros(self.num_envs, dtype=bool)
+        self._autoreset = np.zeros(num_envs, dtype=bool)
         self._ckpt = None
         self.closed = False
 
-    # ------------------------------------------------------------------------------------------
     def _reset_envs(self, mask):
         seeds = self._seeds
         if self.checkpoint:
@@ -83,21 +62,11 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
             if self._ckpt is None:
                 self._ckpt = read_checkpoint(path)
             ck = self._ckpt
-            idx = np.array([pick_checkpoint_episode(ck["num_episodes"], s) for s in seeds])
-            self.sim.reset_from_arrays(ck["b"][idx], ck["u"][idx], ck["w"][idx], mask=mask)
+            fixed = getattr(self, "checkpoint_idx", None)
+            idx = np.array([pick_checkpoint_episode(ck["num_episodes"], s) if fixed is None else fixed for s in seeds])
+            self.sim.reset_from_arrays(*[ck[f][idx] for f in self._fields], mask=mask)
         else:
             self.sim.reset(np.asarray(seeds, dtype=np.uint64), mask=mask)
-
-    def _infos(self):
-        t, step = self.sim.get_info()
-        nus, nuo = self.sim.get_nusselt()
-        ones = np.ones(self.num_envs, dtype=bool)
-        info = {"t": t, "_t": ones, "step": step, "_step": ones.copy(),
-                "nusselt_state": nus, "_nusselt_state": ones.copy(), "nusselt_obs": nuo, "_nusselt_obs": ones.copy()}
-        if self.info_state:
-            info["state"] = self.sim.get_state(self._nch)
-            info["_state"] = ones.copy()
-        return info, t, nuo
 
     def reset(self, *, seed=None, options=None):
         super().reset(seed=seed)
@@ -115,11 +84,11 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
             self._seeds = np.array([old[i] if s[i] is None else s[i] for i in range(n)], dtype=np.uint64)
         self._reset_envs(None)
         self._autoreset[:] = False
-        info, _, _ = self._infos()
-        return self.sim.get_obs(self._nch), info
+        info, _, _ = self._stacked_info()
+        return self._observations(), info
 
     def step(self, actions):
-        a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.heater_segments)
+        a = np.asarray(actions, dtype=np.float32).reshape((self.num_envs,) + tuple(self.single_action_space.shape))
         if not self.sim.step(a):
             bad = np.nonzero(self.sim.get_flags())[0]
             if not np.all(self._autoreset[bad]):         # an env that is re-initialised below may be ignored
@@ -127,14 +96,65 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
         resetting = self._autoreset.copy()
         if resetting.any():                              # NEXT_STEP autoreset: these envs restart now, their action is ignored
             self._reset_envs(resetting.astype(np.uint8))
-        info, t, nuo = self._infos()
-        obs = self.sim.get_obs(self._nch)
-        rewards = -nuo
+        info, t, nusselt = self._stacked_info()
+        rewards = -nusselt
         rewards[resetting] = 0.0
         terminated = np.zeros(self.num_envs, dtype=bool)
         truncated = (t >= self.episode_length) & ~resetting
         self._autoreset = truncated.copy()
-        return obs, rewards, terminated, truncated, info
+        return self._observations(), rewards, terminated, truncated, info
+
+    def step_device(self, actions_device_ptr):
+        """Advance all envs with actions already on the device (float32, batch-major); no host copy,
+        no autoreset, asynchronous on the simulation's stream."""
+        self.sim.step_dev(actions_device_ptr)
+
+    def close(self, **kwargs):
+        if getattr(self, "sim", None) is not None:
+            self.sim.close()
+            self.sim = None
+        self.closed = True
+
+
+class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
+    def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
+                 state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
+                 use_gpu=True, checkpoint=None, render_mode=None, device=0, info_state=True, **_ignored):
+        self.num_envs = int(num_envs)
+        self.ra = rayleigh_number
+        self.observation_shape = list(observation_shape)
+        self.state_shape = list(state_shape)
+        self.temperature_difference = [1, 2]
+        self.heater_segments = heater_segments
+        self.heater_limit = heater_limit
+        self.heater_duration = heater_duration
+        self.include_pressure = pressure
+        self.episode_steps = int(episode_length / heater_duration)
+        self.info_state = info_state
+        self.single_action_space, self.single_observation_space = build_spaces(self.observation_shape, heater_segments,
+                                                                               heater_limit, pressure)
+        ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
+        self.sim = _native.NativeSim(batch=self.num_envs, device=device,
+                                     **sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments,
+                                                  heater_limit, heater_duration))
+        if np.ndim(rayleigh_number) > 0:                 # per-env Rayleigh numbers (Ra sweeps)
+            self.sim.set_rayleigh(np.asarray(rayleigh_number, dtype=np.float64))
+        self._nch = 5 if pressure else 3
+        self._finish_init(self.num_envs, episode_length, checkpoint, render_mode)
+
+    def _observations(self):
+        return self.sim.get_obs(self._nch)
+
+    def _stacked_info(self):
+        t, step = self.sim.get_info()
+        nus, nuo = self.sim.get_nusselt()
+        ones = np.ones(self.num_envs, dtype=bool)
+        info = {"t": t, "_t": ones, "step": step, "_step": ones.copy(),
+                "nusselt_state": nus, "_nusselt_state": ones.copy(), "nusselt_obs": nuo, "_nusselt_obs": ones.copy()}
+        if self.info_state:
+            info["state"] = self.sim.get_state(self._nch)
+            info["_state"] = ones.copy()
+        return info, t, nuo
 
     # -- device-resident rollout API (zero-copy PyTorch-ROCm tensors) --------------------------------
     def device_views(self):
@@ -142,11 +162,6 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
         B, (oz, ox), (nz, nx) = self.num_envs, self.observation_shape, self.state_shape
         return {"obs": DeviceArray(p["obs"], (B, 5, oz, ox), "<f4", self), "state": DeviceArray(p["state"], (B, 5, nz, nx), "<f4", self),
                 "nusselt": DeviceArray(p["nusselt"], (B, 2), "<f8", self), "flags": DeviceArray(p["flags"], (B,), "<i4", self)}
-
-    def step_device(self, actions_device_ptr):
-        """Advance all envs with actions already on the device ([B][heaters] float32); no host copy,
-        no autoreset, asynchronous on the simulation's stream."""
-        self.sim.step_dev(actions_device_ptr)
 
     def render(self):
         """One frame per env, as gymnasium's vector envs return them (a tuple): the temperature field through the
@@ -161,8 +176,41 @@ class RayleighBenardConvection2DVectorEnv(gym.vector.VectorEnv):
         temp = self.sim.get_state(1)[:, 0]                                   # (B, nz, nx)
         return tuple(temperature_image(t, 1, 2 + self.heater_limit).transpose(1, 0, 2) for t in temp)
 
-    def close(self, **kwargs):
-        if getattr(self, "sim", None) is not None:
-            self.sim.close()
-            self.sim = None
-        self.closed = True
+
+class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
+    """Batched 3D env (BASELINE.json configs[4]: 32 envs per GPU): constructor kwargs of the reference's 3D env
+    (rbc3D.py:43-61) plus num_envs / device; observations are the float32 states (B, 4, Nz, Ny, Nx), info {t, step, nusselt}."""
+    metadata = {"render_modes": [], "autoreset_mode": "NextStep"}
+    _fields = ("b", "u", "v", "w")
+
+    def __init__(self, num_envs=1, rayleigh_number=2500, prandtl_number=0.7, domain=(2, 4 * np.pi, 4 * np.pi),
+                 state_shape=(16, 32, 32), temperature_difference=(1, 2), heater_segments=8, heater_limit=0.9,
+                 heater_duration=0.125, episode_length=300, dt_solver=0.01, use_gpu=True, checkpoint=None, checkpoint_idx=None,
+                 render_mode=None, device=0, **_ignored):
+        from .envs.rbc3D import build_spaces3d
+        self.num_envs = int(num_envs)
+        self.ra, self.pr = rayleigh_number, prandtl_number
+        self.dim = 3
+        self.domain, self.state_shape = list(domain), list(state_shape)
+        self.temperature_difference = list(temperature_difference)
+        self.heater_segments, self.heater_limit, self.heater_duration = heater_segments, heater_limit, heater_duration
+        self.dt_solver = dt_solver
+        self.checkpoint_idx = checkpoint_idx
+        self.single_action_space, self.single_observation_space = build_spaces3d(state_shape, temperature_difference,
+                                                                                 heater_segments, heater_limit)
+        ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
+        self.sim = _native.NativeSim3D(batch=self.num_envs, device=device, shape=tuple(state_shape), domain=tuple(domain), ra=ra0,
+                                       pr=float(prandtl_number), t_diff=tuple(temperature_difference), heaters=heater_segments,
+                                       heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver)
+        if np.ndim(rayleigh_number) > 0:
+            self.sim.set_rayleigh(np.asarray(rayleigh_number, dtype=np.float64))
+        self._finish_init(self.num_envs, episode_length, checkpoint, render_mode)
+
+    def _observations(self):
+        return self.sim.get_state()
+
+    def _stacked_info(self):
+        t, step = self.sim.get_info()
+        nu = self.sim.get_nusselt()
+        ones = np.ones(self.num_envs, dtype=bool)
+        return {"t": t, "_t": ones, "step": step, "_step": ones.copy(), "nusselt": nu, "_nusselt": ones.copy()}, t, nu.copy()

@@ -350,3 +350,35 @@ def test_ra_sweep_ensembles_match_the_reference_episode_statistics():
     assert abs(z(10000000, "nusselt_state")) < 4.0
     k2 = np.abs(got[10000]["ke"] - ref[10000]["ke"].mean()) < 1e-4            # Ra=1e4: steady; see the from-rest ensemble test
     assert k2.sum() > 0.8 * k2.size and abs(got[10000]["ke"][k2].mean() / ref[10000]["ke"].mean() - 1) < 3e-6
+
+
+def test_3d_vector_env_matches_single_envs_and_autoresets(gym):
+    """Batched 3D env (BASELINE.json configs[4] shape of use): env i of make_vec(seed=s) is the single env seeded s+i;
+    NEXT_STEP autoreset; info keys {t, step, nusselt} stacked with masks."""
+    ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
+    kw = dict(state_shape=(8, 16, 16), heater_duration=0.05, episode_length=0.4, rayleigh_number=3000)
+    n = 3
+    venv = gym.make_vec(ID3, num_envs=n, **kw)
+    assert venv.num_envs == n and venv.single_action_space.shape == (8, 8) and venv.observation_space.shape == (n, 4, 8, 16, 16)
+    singles = [gym.make(ID3, **kw) for _ in range(n)]
+    obs, info = venv.reset(seed=11)
+    for i, e in enumerate(singles):
+        o, _ = e.reset(seed=11 + i)
+        assert np.array_equal(o, obs[i])
+    assert set(info) == {"t", "_t", "step", "_step", "nusselt", "_nusselt"} and np.all(info["step"] == 1)
+    rng = np.random.default_rng(2)
+    truncs = []
+    for k in range(3):
+        a = rng.uniform(-1, 1, (n, 8, 8)).astype(np.float32)
+        obs, rew, term, trunc, info = venv.step(a)
+        truncs.append(trunc.copy())
+        if k < 2:                                           # step 2 is the autoreset step: the batched envs restart there
+            for i, e in enumerate(singles):
+                o, r, _, tr, inf = e.step(a[i])
+                assert np.array_equal(o, obs[i]) and r == rew[i] and tr == trunc[i] and inf["t"] == info["t"][i]
+        assert not term.any()
+    assert not truncs[0].any() and truncs[1].all()          # t = 0.4 (2 steps x 0.05 x t_ff = 4) reaches episode_length
+    assert not truncs[2].any() and np.all(rew == 0) and np.all(info["t"] == 0) and np.all(info["step"] == 1)   # autoreset step
+    venv.close()
+    for e in singles:
+        e.close()
