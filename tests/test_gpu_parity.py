@@ -200,7 +200,9 @@ def test_masked_reset_and_nan_flag(native, ckpt_ra1e4):
     dict(nz=32, heaters=24, heater_limit=0.9, obs=(4, 24), dt_solver=0.03, dt_control=0.2, ra=5e3, lx=3 * np.pi),
     dict(nz=64, heaters=32, heater_limit=0.3, obs=(16, 96), dt_solver=0.025, dt_control=0.11, ra=4e4, pr=1.0),
     dict(nz=64, heaters=1, heater_limit=0.75, obs=(2, 1), dt_solver=0.03, dt_control=0.09, ra=1e4),
-], ids=["96x48", "96x32", "96x64-32heaters", "96x64-1heater"])
+    dict(nz=64, heaters=10, heater_limit=0.75, obs=(8, 48), dt_solver=0.03, dt_control=0.09, ra=1e4),   # segment edges fall inside cells: cubic blends
+    dict(nz=32, heaters=7, heater_limit=0.6, obs=(8, 48), dt_solver=0.03, dt_control=0.06, ra=1e4),
+], ids=["96x48", "96x32", "96x64-32heaters", "96x64-1heater", "96x64-10heaters-blends", "96x32-7heaters-blends"])
 def test_non_default_configurations_match_oracle(native, oracle, cfg):
     """Every compiled grid (96x64, 96x48, 96x32) and the run-time parameters of initialize_simulation
     (rbc_sim2D_api.jl:17-70: Ra, Pr, domain, plate temperatures, heaters, heater_limit, sensor grid, solver / control
