@@ -742,8 +742,9 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             STAMP(1);
 #pragma unroll
             for (int r = 0; r < CZ; r += 2) {                                         // lands under the u pass
-                const dbl2 v = park_b[r / 2];
-                g0b[r] = use_g0 ? v.x : 0.0; g0b[r + 1] = use_g0 ? v.y : 0.0;
+                dbl2 v; v.x = 0.0; v.y = 0.0;
+                if (use_g0) v = park_b[r / 2];                                        // uniform branch: zeta^1 = 0 needs no G^-
+                g0b[r] = v.x; g0b[r + 1] = v.y;
             }
             // ======================= u tendency (walks down the chunk) ==============================
             {
@@ -814,8 +815,9 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             // ======================= b tendency (walks up) ===========================================
 #pragma unroll
             for (int r = 0; r < CZ; r += 2) {                                         // lands under the b pass
-                const dbl2 v = park_w[r / 2];
-                g0w[r] = use_g0 ? v.x : 0.0; g0w[r + 1] = use_g0 ? v.y : 0.0;
+                dbl2 v; v.x = 0.0; v.y = 0.0;
+                if (use_g0) v = park_w[r / 2];
+                g0w[r] = v.x; g0w[r + 1] = v.y;
             }
             {
                 double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
