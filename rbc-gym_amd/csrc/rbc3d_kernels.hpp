@@ -432,10 +432,13 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
 // and every cross-column stencil value is an LDS read; each thread keeps its own column's z windows and the
 // carried face fluxes in registers.  Two kernels: (u, v) share the planes u, v, w(k+1); (w, b) the planes w, b.
 // About 24 global loads per cell for all four fields (marching kernels: ~90, cell-per-thread: ~380).
+#ifndef RBC_KT3
+#define RBC_KT3 8
+#endif
 #ifndef RBC_TILE_WAVES
 #define RBC_TILE_WAVES 2      // waves per SIMD the tiled kernels are compiled for (register budget 512 / waves)
 #endif
-constexpr int KT3 = 8;                 // levels per workgroup
+constexpr int KT3 = RBC_KT3;                 // levels per workgroup
 constexpr int TY3 = 8;                 // tile rows
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
 constexpr int PLANE3 = (TY3 + 6) * NXP3;
