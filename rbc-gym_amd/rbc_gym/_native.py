@@ -293,7 +293,7 @@ class NativeSim3D:
     """A batch of B 3D envs on one GPU (rbc_sim3D_api.jl semantics; array shapes (nz, ny, nx))."""
 
     def __init__(self, batch=1, device=0, shape=(16, 32, 32), domain=(2.0, 4 * np.pi, 4 * np.pi), ra=2500.0, pr=0.7,
-                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01):
+                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01, random_kick=None):
         self.lib = load_library()
         cfg = default_config()
         nz, ny, nx = shape
@@ -305,6 +305,8 @@ class NativeSim3D:
         cfg.heaters, cfg.heater_limit = int(heaters), float(heater_limit)
         cfg.dt_control, cfg.dt_solver = float(dt_control), float(dt_solver)
         cfg.obs_nx, cfg.obs_nz = int(nx), int(nz)
+        if random_kick is not None:
+            cfg.random_kick = float(random_kick)
         cfg.batch, cfg.device = int(batch), int(device)
         self.cfg = cfg
         self.h = _vp()

@@ -88,3 +88,24 @@ def test_generate_checkpoints_on_device_and_reset_from_them(tmp_path):
     st = info["state"]
     assert any(np.allclose(st[0], r["b"][e].astype(np.float32)) for e in range(4))
     env.close()
+
+
+@pytest.mark.gpu
+def test_generate_3d_checkpoints_and_reset_from_them(tmp_path):
+    from rbc_gym.generate import generate_checkpoints_3d
+    import rbc_gym  # noqa: F401
+    from rbc_gym._gym import gym
+    p = generate_checkpoints_3d(str(tmp_path / "train"), ra=2500, random_inits=3, seed=42, n=(16, 16, 8), duration=2.0)
+    assert os.path.basename(p) == "3D_ckpt_ra2500.h5"
+    r = ck.read_checkpoint(p)
+    assert r["num_episodes"] == 3 and r["start_seed"] == 42
+    assert r["b"].shape == (3, 8, 16, 16) and r["v"].shape == (3, 8, 16, 16) and r["w"].shape == (3, 9, 16, 16)
+    assert np.all(r["w"][:, 0] == 0) and np.all(r["w"][:, -1] == 0)
+    dx = dy = 4 * np.pi / 16
+    div = ((np.roll(r["u"], -1, axis=3) - r["u"]) / dx + (np.roll(r["v"], -1, axis=2) - r["v"]) / dy
+           + (r["w"][:, 1:] - r["w"][:, :-1]) / (2.0 / 8))
+    assert np.abs(div).max() < 1e-11
+    env = gym.make("rbc_gym/RayleighBenardConvection3D-v0", state_shape=(8, 16, 16), rayleigh_number=2500, checkpoint=p, checkpoint_idx=2)
+    obs, _ = env.reset(seed=0)
+    assert np.array_equal(obs[0], r["b"][2].astype(np.float32)) and np.array_equal(obs[3], r["w"][2][:8].astype(np.float32))
+    env.close()
