@@ -577,9 +577,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #endif
     const int c = tid / NX, i = tid - c * NX;
     const int k0 = c * CZ;
-    const bool bot = (c == 0), top = (c == G::NC - 1);
-    const int ip1 = (i + 1 == NX) ? 0 : i + 1, ip2 = (ip1 + 1 == NX) ? 0 : ip1 + 1, ip3 = (ip2 + 1 == NX) ? 0 : ip2 + 1;
-    const int im1 = (i == 0) ? NX - 1 : i - 1, im2 = (im1 == 0) ? NX - 1 : im1 - 1, im3 = (im2 == 0) ? NX - 1 : im2 - 1;
+    const bool top = (c == G::NC - 1);
 
     const double dx = P.dx, dz = P.dz, rdx = P.rdx, rdz = P.rdz;
     const double nu = P.nu_kappa[2 * env], kap = P.nu_kappa[2 * env + 1];
