@@ -26,6 +26,7 @@
 #ifndef RBC_HIP_H
 #define RBC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -90,6 +91,12 @@ int  rbc_set_rayleigh(rbc_handle *h, const double *ra);
    clipped to [-maxval, maxval] if clip != 0.  nch <= 5 channels (b,u,w,pHY',pNHS); channels >= nch stay raw;
    nch = 0 switches the transform off.  Takes effect from the next reset/step; rbc_get_state is never transformed. */
 int  rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip);
+
+/* Page-locked host buffers for the rbc_get_* outputs: a pageable destination limits the float32 state copy of 1024
+   envs (75 MB) to the driver's staging rate, a pinned one takes it at PCIe speed.  Plain helpers over hipHostMalloc /
+   hipHostFree; any rbc_get_* accepts either kind of pointer.                                                        */
+void *rbc_host_alloc(size_t bytes);
+void  rbc_host_free(void *p);
 
 /* initialize_simulation (api:17-70).  mask[B] (NULL = all): which envs to reset.
    Random IC (rbc_sim2D.jl:163-171) from the library's counter-based RNG, seeds[B].        */

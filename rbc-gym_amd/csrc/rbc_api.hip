@@ -526,6 +526,18 @@ int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const doubl
     return RBC_OK;
 }
 
+void *rbc_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void rbc_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int rbc_get_obs(rbc_handle *h, float *out, int nch)
 {
     if (int rc = check_handle(h)) return rc;

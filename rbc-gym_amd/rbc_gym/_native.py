@@ -47,6 +47,8 @@ SYMBOLS = {
     "rbc_synchronize": (C.c_int, [_vp]),
     "rbc_set_rayleigh": (C.c_int, [_vp, _dp]),
     "rbc_set_obs_normalization": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int]),
+    "rbc_host_alloc": (_vp, [C.c_size_t]),
+    "rbc_host_free": (None, [_vp]),
     "rbc_reset": (C.c_int, [_vp, _u8p, _u64p]),
     "rbc_reset_from_arrays": (C.c_int, [_vp, _u8p, _dp, _dp, _dp]),
     "rbc_step": (C.c_int, [_vp, _fp]),
@@ -127,6 +129,32 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+class _PinnedBlock:
+    """owner of one hipHostMalloc block; numpy arrays made from it keep it alive through their .base chain"""
+
+    def __init__(self, lib, nbytes):
+        self.lib, self.ptr, self.nbytes = lib, lib.rbc_host_alloc(nbytes), nbytes
+        if not self.ptr:
+            raise MemoryError(f"rbc_host_alloc({nbytes}) failed")
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.rbc_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array over page-locked host memory (rbc_host_alloc): a fast destination for get_state/get_obs(out=...)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    block = _PinnedBlock(load_library(), max(n, 1))
+    return np.asarray(block)[:n].view(dt).reshape(shape)
 
 
 def default_config():
@@ -231,8 +259,10 @@ class NativeSim:
         self._check(self.lib.rbc_get_obs(self.h, _ptr(o, _fp), nch))
         return o
 
-    def get_state(self, nch=3):
-        o = np.empty((self.B, nch, self.nz, self.nx), np.float32)
+    def get_state(self, nch=3, out=None):
+        """float32 (B, nch, nz, nx); `out` may be a caller-owned array of that shape, e.g. from pinned_empty()"""
+        o = np.empty((self.B, nch, self.nz, self.nx), np.float32) if out is None else out
+        assert o.shape == (self.B, nch, self.nz, self.nx) and o.dtype == np.float32 and o.flags.c_contiguous
         self._check(self.lib.rbc_get_state(self.h, _ptr(o, _fp), nch))
         return o
 

@@ -382,3 +382,19 @@ def test_3d_vector_env_matches_single_envs_and_autoresets(gym):
     venv.close()
     for e in singles:
         e.close()
+
+
+def test_pinned_info_state_matches_fresh_arrays(gym):
+    """info_state="pinned": info["state"] arrives in page-locked buffers (rbc_host_alloc) that rotate; same values."""
+    a = gym.make_vec(ID, num_envs=4, heater_duration=0.3, info_state=True)
+    b = gym.make_vec(ID, num_envs=4, heater_duration=0.3, info_state="pinned")
+    a.reset(seed=2); b.reset(seed=2)
+    act = np.random.default_rng(0).uniform(-1, 1, (4, 12)).astype(np.float32)
+    seen = []
+    for _ in range(4):
+        _, _, _, _, ia = a.step(act)
+        _, _, _, _, ib = b.step(act)
+        assert np.array_equal(ia["state"], ib["state"]) and ib["state"].dtype == np.float32
+        seen.append(ib["state"])
+    assert seen[0] is not seen[1] and seen[3].__array_interface__["data"][0] == seen[0].__array_interface__["data"][0]   # 3 buffers rotate
+    a.close(); b.close()
