@@ -55,8 +55,9 @@ def single(args):
 
 def vector(args):
     n, steps = _int(args, 0, 6), _int(args, 1, 100)
-    env = gym.make_vec(ENV2D, num_envs=n, vectorization_mode="async", vector_kwargs={"copy": True, "daemon": True},
-                       render_mode="rgb_array")
+    # no vectorization_mode: gymnasium then takes the id's vector_entry_point, the device-batched env ("async" would
+    # make real gymnasium fork one process and one GPU handle per env, as the reference does with Julia runtimes)
+    env = gym.make_vec(ENV2D, num_envs=n, render_mode="rgb_array")
     obs, info = env.reset()
     print(f"Observation shape: {obs.shape}")
     t0 = time.perf_counter()
