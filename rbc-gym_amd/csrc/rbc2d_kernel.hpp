@@ -932,7 +932,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 for (int r = 0; r < CZ; r += 2) { dbl2 v; v.x = g0w[r]; v.y = g0w[r + 1]; park_w[r / 2] = v; }
             }
         };
-        if (wall_wave) tendencies(std::true_type{}); else tendencies(std::false_type{});
+        if (wall_wave) {
+            __builtin_amdgcn_s_setprio(3);       // the wall copy is the longer one: let it win issue arbitration on its SIMD
+            tendencies(std::true_type{});
+            __builtin_amdgcn_s_setprio(0);
+        } else tendencies(std::false_type{});
         if (dbg) return;
         STAMP(4);
         lds_barrier();   // every read of the old state is done
