@@ -152,15 +152,21 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
         for (int ph = 0; ph < 3; ++ph) {
             double *cur = s->st[s->cur], *nxt = s->st[s->cur ^ 1];
             hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
-            const int tile_threads = g.nx * rbc3::TY3;
-            const int tile_plane = (rbc3::TY3 + 6) * g.nx;
-            if (!h->no_tile && g.nz % rbc3::KT3 == 0 && g.ny % rbc3::TY3 == 0 && tile_threads <= 512 && tile_threads % 64 == 0 && g.nx <= rbc3::NXP3 &&
-                tile_plane <= 2 * tile_threads) {                // LDS-tiled kernels: planes staged once per level
-                const dim3 gt((unsigned)((size_t)B * (g.ny / rbc3::TY3) * (g.nz / rbc3::KT3))), bt(tile_threads);
-                hipLaunchKernelGGL(rbc3::k3_tile_uv<2>, gt, bt, 3 * rbc3::PLANE3 * sizeof(double), h->stream, g, cur, nxt, s->gm, s->phy,
-                                   h->d_ra, d, gam[ph], zet[ph]);
-                hipLaunchKernelGGL(rbc3::k3_tile_wb<2>, gt, bt, 2 * rbc3::PLANE3 * sizeof(double), h->stream, g, cur, nxt, s->gm, s->actT,
-                                   h->d_ra, d, gam[ph], zet[ph]);
+            auto tiles_fit = [&](int ty, int kt, int maxt) {
+                const int thr = g.nx * ty;
+                return !h->no_tile && g.nz % kt == 0 && g.ny % ty == 0 && thr <= maxt && thr % 64 == 0 && g.nx <= rbc3::NXP3 &&
+                       (ty + 6) * g.nx <= 2 * thr;
+            };
+            if (tiles_fit(16, 4, 768)) {                       // LDS-tiled kernels: planes staged once per level
+                const dim3 gt((unsigned)((size_t)B * (g.ny / 16) * (g.nz / 4))), bt(g.nx * 16);
+                const size_t pb = (size_t)(16 + 6) * rbc3::NXP3 * sizeof(double);
+                hipLaunchKernelGGL((rbc3::k3_tile_uv<16, 4, 2, 768, 3>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->phy, h->d_ra, d, gam[ph], zet[ph]);
+                hipLaunchKernelGGL((rbc3::k3_tile_wb<16, 4, 2, 768, 3>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph]);
+            } else if (tiles_fit(8, 8, 512)) {
+                const dim3 gt((unsigned)((size_t)B * (g.ny / 8) * (g.nz / 8))), bt(g.nx * 8);
+                const size_t pb = (size_t)(8 + 6) * rbc3::NXP3 * sizeof(double);
+                hipLaunchKernelGGL((rbc3::k3_tile_uv<8, 8, 2, 512, 2>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->phy, h->d_ra, d, gam[ph], zet[ph]);
+                hipLaunchKernelGGL((rbc3::k3_tile_wb<8, 8, 2, 512, 2>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph]);
             } else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
                 const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
                 hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);

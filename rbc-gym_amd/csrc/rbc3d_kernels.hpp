@@ -432,18 +432,11 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
 // and every cross-column stencil value is an LDS read; each thread keeps its own column's z windows and the
 // carried face fluxes in registers.  Two kernels: (u, v) share the planes u, v, w(k+1); (w, b) the planes w, b.
 // About 24 global loads per cell for all four fields (marching kernels: ~90, cell-per-thread: ~380).
-#ifndef RBC_KT3
-#define RBC_KT3 8
-#endif
-#ifndef RBC_TILE_WAVES
-#define RBC_TILE_WAVES 2      // waves per SIMD the tiled kernels are compiled for (register budget 512 / waves)
-#endif
-constexpr int KT3 = RBC_KT3;                 // levels per workgroup
-constexpr int TY3 = 8;                 // tile rows
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
-constexpr int PLANE3 = (TY3 + 6) * NXP3;
 
+template <int TY3, int KT3>
 struct TileGeo {
+    static constexpr int PLANE3 = (TY3 + 6) * NXP3;
     int nx, ny, nz, pl, rows, plane, tiles, chunks, env, j0, k0, i, jl, j, tid, nthreads;
     __device__ __forceinline__ TileGeo(const Geo3 &g)
     {
@@ -462,14 +455,14 @@ struct TileGeo {
     }
 };
 
-template <int NPF>
-__device__ __forceinline__ void tile_fetch(const TileGeo &t, const double *lev, double (&pf)[NPF])
+template <int NPF, class TG>
+__device__ __forceinline__ void tile_fetch(const TG &t, const double *lev, double (&pf)[NPF])
 {
 #pragma unroll
     for (int q = 0; q < NPF; ++q) { const int idx = t.tid + q * t.nthreads; pf[q] = (idx < t.plane) ? lev[t.src(idx)] : 0.0; }
 }
-template <int NPF>
-__device__ __forceinline__ void tile_store(const TileGeo &t, double *dst, const double (&pf)[NPF])
+template <int NPF, class TG>
+__device__ __forceinline__ void tile_store(const TG &t, double *dst, const double (&pf)[NPF])
 {
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
@@ -478,13 +471,16 @@ __device__ __forceinline__ void tile_store(const TileGeo &t, double *dst, const 
     }
 }
 
-// (u, v): launch with blockDim = nx * TY3, grid = B * (ny/TY3) * (nz/KT3), LDS = 3 planes
-template <int NPF>
-__global__ void __launch_bounds__(512, RBC_TILE_WAVES) k3_tile_uv(Geo3 g, const double *cur, double *nxt, double *gm, const double *phy,
+// (u, v): launch with blockDim = nx * TY3, grid = B * (ny/TY3) * (nz/KT3), LDS = 3 planes.  Two shapes are built:
+// 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
+// (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
+__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *cur, double *nxt, double *gm, const double *phy,
                                                   const double *nu_kappa, double dt, double gam, double zet)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo t(g);
+    const TileGeo<TY3, KT3> t(g);
+    constexpr int PLANE3 = TileGeo<TY3, KT3>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PU = tile_sm, *PV = tile_sm + PLANE3, *PW = tile_sm + 2 * PLANE3;        // u(k), v(k), w(k+1)
     constexpr int IU = 0, IV = PLANE3, IW = 2 * PLANE3;
@@ -614,12 +610,13 @@ __global__ void __launch_bounds__(512, RBC_TILE_WAVES) k3_tile_uv(Geo3 g, const 
 }
 
 // (w, b): same launch shape, LDS = 2 planes (w and b at the current level)
-template <int NPF>
-__global__ void __launch_bounds__(512, RBC_TILE_WAVES) k3_tile_wb(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
+__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
                                                   const double *nu_kappa, double dt, double gam, double zet)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo t(g);
+    const TileGeo<TY3, KT3> t(g);
+    constexpr int PLANE3 = TileGeo<TY3, KT3>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PW = tile_sm, *PB = tile_sm + PLANE3;
     constexpr int IW = 0, IB = PLANE3;

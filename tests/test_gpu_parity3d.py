@@ -166,11 +166,17 @@ def test_flowstats_pin_p4(native):
     assert np.all(nus[200:].max(0).reshape(seeds, len(ras)) < 1.25 * 0.2211 * np.array(ras) ** 0.2742 + 1.0)
 
 
-def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch):
+@pytest.mark.parametrize("shape", [SHAPE, (16, 32, 32)], ids=["tiles-8x8", "tiles-16x4"])
+def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch, shape):
     """The LDS-tiled tendency kernels (nz % 8 == 0, ny % 8 == 0), the z-marching ones (nz % 4 == 0; RBC_NO_TILE=1) and
     the cell-per-thread ones (any grid; RBC_NO_MARCH=1) evaluate the same expressions; a grid with nz = 10 takes the
     generic path and is checked against the oracle."""
-    ic = _developed_state(o3, 5)
+    o = o3.Oracle3D(ra=5000.0, shape=shape, domain=DOMAIN, kick=0.2)
+    o.reset_random(5)
+    o.set_action(np.zeros((8, 8), np.float32)); o.update_state()
+    for _ in range(2):
+        o.substep(0.04)
+    ic = o.fields()
     act = np.random.default_rng(6).uniform(-1, 1, (1, 8, 8)).astype(np.float32)
     outs = []
     # LDS-tiled / z-marching / cell-per-thread tendencies; last: the unpacked Poisson path (one FFT per slab)
@@ -178,17 +184,24 @@ def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch):
         monkeypatch.setenv("RBC_NO_TILE", no_tile)
         monkeypatch.setenv("RBC_NO_MARCH", no_march)
         monkeypatch.setenv("RBC_NO_PAIR", no_pair)
-        sim = native.NativeSim3D(batch=1, shape=SHAPE, domain=DOMAIN, ra=5000.0, dt_control=0.03, dt_solver=0.01)
-        sim.reset_from_arrays(*[x[None] for x in ic])
-        assert sim.step(act)
+        sim = native.NativeSim3D(batch=2, shape=shape, domain=DOMAIN, ra=5000.0, dt_control=0.03, dt_solver=0.01)
+        sim.reset_from_arrays(*[np.stack([x, x[::1]]) for x in ic])
+        assert sim.step(np.concatenate([act, act]))
         outs.append(sim.get_fields())
         sim.close()
     for other in outs[1:]:
         for x, y in zip(outs[0], other):
             assert rel_l2(x, y) < 1e-12
+    ref = o3.Oracle3D(ra=5000.0, shape=shape, domain=DOMAIN, dt_control=0.03, dt_solver=0.01)
+    ref.reset_from_arrays(*ic)
+    assert ref.step(act[0])
+    for x, y in zip(outs[0], ref.fields()):
+        assert rel_l2(x[0], y) < 1e-11 and np.array_equal(x[0], x[1])          # oracle parity; batch members identical
     monkeypatch.delenv("RBC_NO_TILE")
     monkeypatch.delenv("RBC_NO_PAIR")
     monkeypatch.delenv("RBC_NO_MARCH")
+    if shape != SHAPE:
+        return
     shape = (10, 24, 32)
     o = o3.Oracle3D(ra=5000.0, shape=shape, domain=DOMAIN, kick=0.2, dt_control=0.03, dt_solver=0.01)
     o.reset_random(3)
