@@ -10,12 +10,20 @@ the timed region.  N>1: env instances are sharded across ranks, no data-path col
 scaling: 1024 envs per GPU).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      # without a launcher: starts the N ranks itself (before any GPU call)
+
+The JSON line carries, besides the contract's keys: `roofline` (SURVEY.md 8(d)'s algorithmic-bytes convention, with
+the PMC-measured HBM rate beside it), `roofline_valu` (the physically binding one: fp64 VALU issue), `copy_ceiling`
+(an on-box streaming-copy rate next to the 8 TB/s spec), `cpu_baseline` and `extra` (gym-API rate, configs[4] 3D,
+fp32 variant -- all measured in this run).
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,28 +31,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "rbc-gym_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4             # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9             # peak engine clock; a wave64 fp64 VALU instruction occupies its SIMD for 4 cycles
+FP64_WAVE_INST_PEAK = N_SIMD * CLOCK_HZ / 4      # = 6.144e11 /s  (x 64 lanes x 2 flop = 78.6 TFLOP/s for FMA)
 
 
 # ---------------------------------------------------------------------------------------------
-# CPU baseline: the oracle ("port"), one env per process, on the box's host cores.  Runs BEFORE
-# anything touches the GPU (fork-based pool).
+# CPU baseline: the oracle ("port"), envs spread over ALL host cores of the box.  Runs BEFORE
+# anything touches the GPU (fork-based pool).  SURVEY.md 8(d): B = 64 envs of the bench workload.
 # ---------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    idx, nsteps = args
+    idxs, nsteps, dim = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_py
-    rng = np.random.default_rng(1234 + idx)
-    sim = oracle_py.OracleSim(ra=1e4)
-    sim.reset_random(1234 + idx)
-    sim.step(rng.uniform(-1, 1, 12).astype(np.float32))          # warm-up
+    sims, rngs = [], []
+    for idx in idxs:
+        rng = np.random.default_rng(1234 + idx)
+        if dim == 3:
+            sim = oracle_py.Oracle3D(ra=1e4, shape=(32, 48, 48), dt_control=0.125, dt_solver=0.01)
+        else:
+            sim = oracle_py.OracleSim(ra=1e4)
+        sim.reset_random(1234 + idx)
+        sims.append(sim); rngs.append(rng)
+    shape = (8, 8) if dim == 3 else (12,)
     t0 = time.perf_counter()
     for _ in range(nsteps):
-        sim.step(rng.uniform(-1, 1, 12).astype(np.float32))
+        for sim, rng in zip(sims, rngs):
+            sim.step(rng.uniform(-1, 1, shape).astype(np.float32))
     return time.perf_counter() - t0
 
 
-def cpu_baseline(nsteps=6):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(dim=2, envs=64, nsteps=None, budget_s=12.0):
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py
@@ -53,69 +81,133 @@ def cpu_baseline(nsteps=6):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+    nproc = os.cpu_count() or cores
+    envs = max(envs, cores) if dim == 2 else cores
     ctx = mp.get_context("fork")
+    shards = [list(range(r, envs, cores)) for r in range(cores)]
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        per = pool.map(_cpu_worker, [(i, nsteps) for i in range(cores)])
+        if nsteps is None:            # calibrate: one env-step of every env, then as many as the time budget allows
+            cal = max(pool.map(_cpu_worker, [(s, 1, dim) for s in shards]))
+            nsteps = int(max(1, min(200, budget_s / max(cal, 1e-3))))
+        per = pool.map(_cpu_worker, [(s, nsteps, dim) for s in shards])
     wall = time.perf_counter() - t0
     stepping = max(per)
-    return {"value": cores * nsteps / stepping, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "per_core": nsteps / (sum(per) / len(per)),
-            "sample": f"{cores} envs (one per core) x {nsteps} env-steps of the bench workload (64x96, Ra=1e4, "
-                      f"50 RK3 substeps, random ICs seeds 1234+i, U(-1,1) actions) on the C oracle; "
-                      f"{stepping:.1f} s stepping, {wall:.1f} s wall. Julia reference unavailable on this box "
-                      f"(README.md:62 publishes 0.12 s/step at 34 substeps on one Apple-silicon core)"}
+    what = ("64x96, Ra=1e4, 50 RK3 substeps, random ICs seeds 1234+i, U(-1,1) actions" if dim == 2 else
+            "32x48x48, Ra=1e4, 13 RK3 substeps, random ICs seeds 1234+i, U(-1,1) 8x8 actions")
+    return {"value": envs * nsteps / stepping, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "per_core": envs * nsteps / sum(per), "nproc": nproc, "cpu_model": _cpu_model(),
+            "sample": f"{envs} envs spread over {cores} worker processes (all cores this process may use; nproc={nproc}) x {nsteps} "
+                      f"env-steps of the bench workload ({what}) on the C oracle (oracle/, readable scalar C, direct O(N^2) "
+                      f"DFT in its Poisson solve: a deliberately plain port, a baseline and not a tuned CPU code); "
+                      f"{stepping:.1f} s stepping, {wall:.1f} s wall incl. calibration. Julia reference unavailable on this box "
+                      f"(README.md:62 publishes 0.12 s/step at 34 substeps on one Apple-silicon core = 5.7 env-steps/s at 50)"}
 
 
-def bench3d(args, rank, local_rank, world, dev, red_dev, dist, sharding, _native, np, torch):
+# ---------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`--gpus N` without a launcher: become the launcher.  Runs before this process touches the GPU
+    (torch.cuda.device_count() does not initialise it) and never prints a line of its own."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible; refusing to print a line for "
+                         f"fewer GPUs than asked (use --dist-backend gloo to rehearse with ranks sharing a GPU)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def latest_profile(pattern, match):
+    """newest profiles/<pattern> whose recorded bench configuration matches this run (else None, None)"""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if all(d.get("workload_key", {}).get(k) == v for k, v in match.items()):
+            return d, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def timed_loop(torch, dev, barrier, fn, K):
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for n in range(K):
+        fn(n)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
+
+
+def run_3d(ctx, B, K, W, ra):
     """configs[4]: 3D 32x48x48, Ra=1e4, heater_duration 0.125, dt_solver 0.01 (13 RK3 substeps per env-step)."""
-    B = args.batch if args.batch != 1024 else 32
-    K, W = args.steps, args.warmup
-    sim = _native.NativeSim3D(batch=B, device=local_rank, shape=(32, 48, 48), ra=args.ra)
-    stream = torch.cuda.current_stream(dev)
-    sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)
+    torch, np, _native, sharding = ctx["torch"], ctx["np"], ctx["_native"], ctx["sharding"]
+    dev, rank, world = ctx["dev"], ctx["rank"], ctx["world"]
+    sim = _native.NativeSim3D(batch=B, device=ctx["local_rank"], shape=(32, 48, 48), ra=ra)
     start, count = sharding.shard(world * B, world, rank)
     sim.reset(sharding.env_seeds(1234, start, count))
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     actions = (torch.rand((K + W, B, 8, 8), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).contiguous()
+    torch.cuda.synchronize(dev)          # the sim runs on its own stream: the actions must be complete before it reads them
     stride = B * 64 * 4
     for n in range(W):
         sim.step_dev(actions.data_ptr() + n * stride)
     sim.set_profiling(K)
-    torch.cuda.synchronize(dev)
-    sharding.barrier(dist if world > 1 else None)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for n in range(K):
-        sim.step_dev(actions.data_ptr() + (W + n) * stride)
-    torch.cuda.synchronize(dev)
-    sharding.barrier(dist if world > 1 else None)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_loop(torch, dev, ctx["barrier"], lambda n: sim.step_dev(actions.data_ptr() + (W + n) * stride), K)
     ms = sim.profile_read(K)
     nan_envs = int(sim.get_flags().sum())
     nu = sim.get_nusselt()
-    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=red_dev, dist=dist if world > 1 else None)
-    if rank == 0:
-        alg = sim.algorithmic_bytes_per_env_step() * B
-        avg = float(np.mean(ms)) if len(ms) else float("nan")
-        ach = alg / (avg * 1e-3) / 1e9
-        print(json.dumps({
-            "metric": "env-steps/sec (batched 3D RBC 32x48x48 Ra=1e4)", "value": world * B * K / elapsed, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[4]: batched 3D envs, batch={B} per GPU, grid 32x48x48, Ra={args.ra:g}, heater_duration 0.125 "
-                                   "(x t_ff=4) = 13 RK3 substeps per env-step, dt_solver 0.01", "global_batch": world * B,
-                       "parallelism": f"env-sharded x{world} (no collective on the step path)"},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rbc3 stage sequence (hydrostatic, 4x tendency, slab FFT, z sweep, inverse FFT, correct) x 39",
-                         "kernel_ms_avg": avg, "algorithmic_bytes_per_launch": alg,
-                         "note": "algorithmic bytes = 10*F*C*s per substep (F=4, C=73728, s=8) x 13 x batch; 'launch' = one env-step of the batch"},
-            "cpu_baseline": None, "nan_envs": nan_total, "mean_nusselt": float(np.mean(nu))}))
-    if world > 1:
-        dist.destroy_process_group()
+    elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=ctx["red_dev"], dist=ctx["dist"] if world > 1 else None)
+    alg = sim.algorithmic_bytes_per_env_step() * B
+    avg = float(np.mean(ms)) if len(ms) else float("nan")
+    ach = alg / (avg * 1e-3) / 1e9
+    prof, src = latest_profile("*_3d_summary.json", {"dim": 3, "batch": B, "ra": ra})
+    traffic = prof.get("hbm_traffic_bytes_per_env_step_batch") if prof else None
+    sim.close()
+    return {
+        "metric": "env-steps/sec (batched 3D RBC 32x48x48 Ra=1e4)", "value": world * B * K / elapsed, "unit": "env-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[4]: batched 3D envs, batch={B} per GPU, grid 32x48x48, Ra={ra:g}, heater_duration 0.125 "
+                               "(x t_ff=4) = 13 RK3 substeps per env-step, dt_solver 0.01", "global_batch": world * B,
+                   "parallelism": f"env-sharded x{world} (no collective on the step path)"},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": src,
+                     "measured_hbm_gbs": (traffic / (avg * 1e-3) / 1e9) if traffic else None,
+                     "kernel": "rbc3 stage sequence x 39 per env-step (one 'launch' = one env-step of the batch)",
+                     "kernel_ms_avg": avg, "algorithmic_bytes_per_launch": alg,
+                     "note": "algorithmic bytes = 10*F*C*s per substep (F=4, C=73728, s=8) x 13 x batch"},
+        "nan_envs": nan_total, "mean_nusselt": float(np.mean(nu))}
+
+
+def gym_api_rate(ctx, B, steps, info_state):
+    """The gym-level number of SURVEY.md 8(d)'s metric text: B x VectorEnv.step() calls per wall second, host actions in,
+    host observations / rewards / infos out (PCIe inclusive)."""
+    np = ctx["np"]
+    from rbc_gym.vector import RayleighBenardConvection2DVectorEnv
+    venv = RayleighBenardConvection2DVectorEnv(num_envs=B, device=ctx["local_rank"], info_state=info_state, episode_length=10**9)
+    venv.reset(seed=1234)
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, (steps + 1, B, 12)).astype(np.float32)
+    venv.step(acts[0])
+    t0 = time.perf_counter()
+    for n in range(steps):
+        venv.step(acts[n + 1])
+    dt = time.perf_counter() - t0
+    venv.close()
+    return B * steps / dt
 
 
 def main():
@@ -123,27 +215,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="envs per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default 1024; 32 with --dim 3)")
     ap.add_argument("--ra", type=float, default=1e4)
     ap.add_argument("--ra-sweep", type=str, default=None,
                     help="comma list, e.g. 1e4,1e5,1e6: BASELINE.json configs[3] stress case; the GLOBAL batch is split "
                          "into contiguous equal parts, one Rayleigh number each (fixed dt=0.03 as in the reference)")
+    ap.add_argument("--precision", default="f64", choices=("f64", "f32"),
+                    help="arithmetic of the 2D kernel; f64 (the reference's) is the headline, f32 the variant of SURVEY 8(d) C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (copy ceiling, gym-API rate, 3D, fp32)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the N>1 flow with several ranks sharing one GPU")
     ap.add_argument("--dim", type=int, default=2, choices=(2, 3),
                     help="3: BASELINE.json configs[4] (3D 32x48x48, Ra=1e4, 32 envs per GPU); the default line is the 2D configs[1]")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                     # the ranks print the line; this process never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(dim=args.dim)
 
     import numpy as np
     import torch
@@ -164,12 +263,26 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     red_dev = dev if args.dist_backend == "nccl" else None      # gloo reduces host tensors
 
-    B, K, W = args.batch, args.steps, args.warmup
+    def barrier():
+        sharding.barrier(dist if world > 1 else None)
+
+    ctx = dict(torch=torch, np=np, _native=_native, sharding=sharding, dist=dist, dev=dev, red_dev=red_dev, rank=rank,
+               local_rank=local_rank, world=world, barrier=barrier)
+    K, W = args.steps, args.warmup
     if args.dim == 3:
-        return bench3d(args, rank, local_rank, world, dev, red_dev, dist, sharding, _native, np, torch)
-    sim = _native.NativeSim(batch=B, device=local_rank, ra=args.ra)
-    stream = torch.cuda.current_stream(dev)
-    sim.lib.rbc_set_stream(sim.h, stream.cuda_stream)
+        out = run_3d(ctx, args.batch or 32, K, W, args.ra)
+        if rank == 0:
+            out["cpu_baseline"] = cpu
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    B = args.batch or 1024
+    f32 = args.precision == "f32"
+    sim = _native.NativeSim(batch=B, device=local_rank, ra=args.ra, precision=1 if f32 else 0)
+    # the simulation runs on its own (non-blocking) stream; everything torch enqueues for it is completed with a device
+    # synchronisation before the sim reads it, and the timed region is bracketed by device synchronisations
     start, count = sharding.shard(world * B, world, rank)      # weak scaling: B envs on every GPU
     assert count == B
     ra_env = None
@@ -181,45 +294,45 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     actions = (torch.rand((K + W, B, 12), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).contiguous()
+    torch.cuda.synchronize(dev)
     stride = B * 12 * 4
-
-    def barrier():
-        sharding.barrier(dist if world > 1 else None)
 
     for n in range(W):
         sim.step_dev(actions.data_ptr() + n * stride)
     sim.set_profiling(K)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for n in range(K):
-        sim.step_dev(actions.data_ptr() + (W + n) * stride)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_loop(torch, dev, barrier, lambda n: sim.step_dev(actions.data_ptr() + (W + n) * stride), K)
 
     kern_ms = sim.profile_read(K)
     flags = sim.get_flags()
     nan_envs = int(flags.sum())
     nus, _ = sim.get_nusselt()
-
     elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=red_dev, dist=dist if world > 1 else None)
+    alg_bytes = sim.algorithmic_bytes_per_env_step() * B          # per launch
+    sim.close()
 
     if rank == 0:
-        traffic, traffic_src = None, None
-        try:                       # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-            import glob
-            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))[-1]
-            summ = json.load(open(latest))
-            if summ.get("bench_line_under_profiler", {}).get("config", {}).get("global_batch") == world * B or world == 1:
-                traffic, traffic_src = summ.get("hbm_traffic_bytes_per_launch"), os.path.relpath(latest, ROOT)
-        except Exception:
-            pass
-        alg_bytes = sim.algorithmic_bytes_per_env_step() * B          # per launch
         avg_ms = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms == avg_ms else None
+        # counters from the separate rocprofv3 --pmc passes, attached only when they were taken on THIS workload
+        key = {"dim": 2, "batch": B, "ra": args.ra, "precision": args.precision, "ra_sweep": args.ra_sweep}
+        prof, prof_src = latest_profile("*_summary.json", key)
+        traffic = prof.get("hbm_traffic_bytes_per_launch") if prof else None
+        sq, sq_src = latest_profile("*_sq_counters.json", key)
+        valu = None
+        if sq:
+            pl = sq["per_launch_mean"]
+            n64 = pl.get("SQ_INSTS_VALU_ADD_F64", 0) + pl.get("SQ_INSTS_VALU_FMA_F64", 0) + pl.get("SQ_INSTS_VALU_MUL_F64", 0)
+            n_all = pl.get("SQ_INSTS_VALU", 0)
+            flop = 64 * (pl.get("SQ_INSTS_VALU_ADD_F64", 0) + 2 * pl.get("SQ_INSTS_VALU_FMA_F64", 0) + pl.get("SQ_INSTS_VALU_MUL_F64", 0))
+            rate = n64 / (avg_ms * 1e-3)
+            valu = {"bound": "valu_fp64_issue", "achieved": rate, "peak": FP64_WAVE_INST_PEAK, "unit": "fp64 wave64-instructions/s",
+                    "frac": rate / FP64_WAVE_INST_PEAK, "fp64_wave_instructions_per_launch": n64, "valu_wave_instructions_per_launch": n_all,
+                    "all_valu_issue_frac": (n_all / (avg_ms * 1e-3)) / FP64_WAVE_INST_PEAK if n_all else None,
+                    "achieved_tflops_fp64": flop / (avg_ms * 1e-3) / 1e12, "peak_tflops_fp64_vector": 78.6,
+                    "source": sq_src,
+                    "note": "instruction counts per launch are constants of the build (SQ_INSTS_VALU_{ADD,FMA,MUL}_F64, separate "
+                            "rocprofv3 --pmc passes); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 instruction. This is the "
+                            "limiter that binds: the state never leaves LDS, HBM carries ~14 % of the algorithmic bytes"}
         out = {
             "metric": "env-steps/sec (batched 2D RBC 64x96 Ra=1e4)",
             "value": world * B * K / elapsed,
@@ -231,7 +344,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": f"configs[1]: batched 2D envs, batch={B} per GPU, grid 64x96, Ra={args.ra:g}, "
                                    "heater_duration 1.5 = 50 RK3 substeps (150 stages) per env-step, dt 0.03",
@@ -240,12 +353,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE)*1024, separate rocprofv3 --pmc passes",
-                         "traffic_source": traffic_src,
-                         "kernel": "rbc2d_kernel<96,64>", "kernel_ms_avg": avg_ms,
+                         "traffic_source": prof_src,
+                         "measured_hbm_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                         "measured_hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "kernel": f"rbc2d_kernel<96,64,{'float' if f32 else 'double'}>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = 10*F*C*s per RK3 substep (F=3,C=6144,s=8) x 50 x batch; the kernel "
-                                 "keeps the state in LDS for the whole control interval: real HBM traffic is ~0.4 MB/env of state and outputs "
-                                 "plus ~10 MB/env of G^- tendencies parked through L2 (write-through stores, reads served by L2)"},
+                         "note": "achieved/frac follow SURVEY.md 8(d)'s convention (algorithmic bytes = 10*F*C*s per RK3 substep, F=3, "
+                                 "C=6144, x 50 x batch, / kernel time): a CONVENTION number for this kernel, which keeps the state in LDS "
+                                 "for the whole control interval and is NOT HBM-bound -- measured_hbm_* is what the memory system "
+                                 "actually carries (state in/out + G^- tendencies parked through L2), roofline_valu the limiter that binds"},
+            "roofline_valu": valu,
             "cpu_baseline": cpu,
             "nan_envs": nan_total,
             "ra_sweep": ({"values": [float(x) for x in args.ra_sweep.split(",")],
@@ -254,6 +371,34 @@ def main():
                          if args.ra_sweep else None),
             "mean_nusselt_state": float(np.mean(nus)),
         }
+        if world == 1 and not args.no_extra:
+            extra = {}
+            try:
+                extra["copy_ceiling"] = _native.copy_ceiling(local_rank)
+                out["roofline"]["on_box_copy_gbs"] = extra["copy_ceiling"]["kernel_gbs"]
+                extra["gym_api_env_steps_per_s"] = {
+                    "no_info_state": gym_api_rate(ctx, B, 5, False), "pinned_info_state": gym_api_rate(ctx, B, 5, "pinned"),
+                    "note": "B x VectorEnv.step() per wall second, host actions in, host obs/reward/info out; 5 steps after 1 warm-up"}
+                d3 = run_3d(ctx, 32, 5, 2, 1e4)
+                extra["config4_3d"] = {k: d3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
+                                                          "nan_envs", "mean_nusselt")}
+                if not f32 and _native.has_precision("f32"):
+                    s32 = _native.NativeSim(batch=B, device=local_rank, ra=args.ra, precision=1)
+                    s32.reset(sharding.env_seeds(1234, 0, B))
+                    for n in range(2):
+                        s32.step_dev(actions.data_ptr() + n * stride)
+                    k32 = min(K, 10)
+                    s32.set_profiling(k32)
+                    e32 = timed_loop(torch, dev, barrier, lambda n: s32.step_dev(actions.data_ptr() + (W + n) * stride), k32)
+                    ms32 = float(np.mean(s32.profile_read(k32)))
+                    alg32 = s32.algorithmic_bytes_per_env_step() * B
+                    extra["fp32_variant"] = {"value": B * k32 / e32, "unit": "env-steps/s", "ms_per_step": e32 / k32 * 1e3, "kernel_ms_avg": ms32,
+                                             "roofline_frac_vs_36.86MB_per_env_step": alg32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "nan_envs": int(s32.get_flags().sum()), "mean_nusselt_state": float(np.mean(s32.get_nusselt()[0]))}
+                    s32.close()
+            except Exception as e:                       # an extra must never take the contract line down with it
+                extra["error"] = f"{type(e).__name__}: {e}"
+            out["extra"] = extra
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBC_ABI_VERSION 1
+#define RBC_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -64,7 +64,12 @@ typedef struct rbc_config {
     int32_t batch;           /* number of env instances B on this device                     */
     int32_t device;          /* HIP device ordinal                                           */
     int32_t write_state;     /* 1: rbc_step also refreshes the float32 full-state buffer     */
+    int32_t precision;       /* arithmetic of the solver: RBC_PRECISION_F64 (0, the reference's Float64, default) or
+                                RBC_PRECISION_F32 (1: float32 state and arithmetic, dim=2 only).
+                                The I/O types of the ABI do not change with it (float64 fields, float32 obs/state).  */
 } rbc_config;
+
+enum { RBC_PRECISION_F64 = 0, RBC_PRECISION_F32 = 1 };
 
 typedef struct rbc_handle rbc_handle;
 
@@ -72,12 +77,17 @@ typedef struct rbc_handle rbc_handle;
 int         rbc_abi_version(void);
 const char *rbc_last_error(void);                 /* thread-local message of the last failure */
 int         rbc_device_count(void);               /* number of visible HIP devices (0 if none) */
+int         rbc_has_precision(int precision);     /* 1 if this build carries kernels for RBC_PRECISION_* */
 void        rbc_default_config(rbc_config *cfg);  /* the gym registry defaults (__init__.py:7-18) */
 
 /* lifetime: replaces gym.make()'s juliacall.newmodule + include (rbc2D.py:111-115) */
 int  rbc_create(const rbc_config *cfg, rbc_handle **out);
 int  rbc_destroy(rbc_handle *h);
-int  rbc_set_stream(rbc_handle *h, void *hip_stream);   /* NULL = the handle's own stream */
+/* Stream all launches of the handle go to.  NULL = the handle's own (non-blocking) stream, which has NO implicit ordering
+   with any other stream: complete what the sim will read (actions written by another stream) before calling rbc_step_dev,
+   and rbc_synchronize (or an event) before another stream reads the rbc_dev_* views.  To run ON the legacy default stream
+   (what PyTorch's default stream, handle 0, is) pass hipStreamLegacy = (void*)1; any other value is a hipStream_t.      */
+int  rbc_set_stream(rbc_handle *h, void *hip_stream);
 void *rbc_get_stream(rbc_handle *h);
 int  rbc_synchronize(rbc_handle *h);
 
@@ -147,6 +157,10 @@ void *rbc_dev_fields(rbc_handle *h);   /* float64 [B][ b(nz*nx) | u(nz*nx) | w((
    durations in milliseconds to ms[0..capacity) and returns how many it wrote (-1 on error). */
 int    rbc_set_profiling(rbc_handle *h, int max_launches);
 int    rbc_profile_read(rbc_handle *h, double *ms, int capacity);
+/* On-box streaming ceiling to report next to the 8 TB/s spec: copies `bytes` (rounded down to 16) from one
+   device buffer to another `iters` times after a warm-up, once with a 16-bytes-per-lane grid-stride copy kernel and once
+   with hipMemcpyAsync device-to-device; rates in GB/s count bytes read + bytes written.  Either output may be NULL.   */
+int    rbc_copy_ceiling(int device, size_t bytes, int iters, double *kernel_gbs, double *memcpy_gbs);
 /* algorithmic HBM bytes of one env-step per env under SURVEY.md 8(d)'s convention          */
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h);
 

@@ -1110,4 +1110,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #endif
 }
 
+// streaming-copy kernel for rbc_copy_ceiling: 16 bytes per lane, grid-stride, 4096 workgroups of 256 threads
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 }  // namespace rbc

@@ -14,6 +14,9 @@ struct rbc3_state {
     double2 *spec = nullptr;
     size_t fft_lds = 0;
     double tff = 1.0;
+    // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" overrides them for the
+    // "does the flowstats pin discriminate the time integrator" experiment; never set in production.
+    double gam[3] = {8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0}, zet[3] = {0.0, -17.0 / 60.0, -5.0 / 12.0};
     // one captured HIP graph per ping-pong parity of the standard env-step (39 stages is odd, so the
     // starting buffer alternates): ~350 launches replayed as one graph launch
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -51,6 +54,12 @@ int create3d(rbc_handle *h)
     g.min_b = c.min_b; g.delta_b = c.delta_b; g.heater_limit = c.heater_limit; g.kick = c.random_kick;
     g.heaters = c.heaters;
     s->tff = c.lz * c.lz;                                    // rbc_sim3D_api.jl:43
+    if (const char *e = std::getenv("RBC_EXPERIMENT_RK3")) {
+        double v[5];
+        if (std::sscanf(e, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
+            s->gam[0] = v[0]; s->gam[1] = v[1]; s->gam[2] = v[2]; s->zet[1] = v[3]; s->zet[2] = v[4];
+        } else return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_RK3 must be g1,g2,g3,z2,z3");
+    }
     factor2(c.nx, s->plan.nx1, s->plan.nx2);
     factor2(c.ny, s->plan.ny1, s->plan.ny2);
     s->fft_lds = ((size_t)2 * c.nx * c.ny + c.nx + c.ny) * sizeof(double2);
@@ -145,7 +154,7 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
     const rbc3::Geo3 &g = s->g;
     const int B = h->B;
     hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(B), dim3(64), 0, h->stream, g, actions_dev, s->actT, 0);
-    const double gam[3] = {8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0}, zet[3] = {0.0, -17.0 / 60.0, -5.0 / 12.0};
+    const double *gam = s->gam, *zet = s->zet;
     const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
     for (int n = 0; n < nsub; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;

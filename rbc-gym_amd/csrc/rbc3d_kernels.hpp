@@ -272,7 +272,9 @@ __global__ void k3_tendency(Geo3 g, const double *cur, double *nxt, double *gm, 
     const size_t foff = (FIELD == 3) ? 0 : ((FIELD == 0) ? (size_t)g.nc : ((FIELD == 1) ? 2 * (size_t)g.nc : 3 * (size_t)g.nc));
     const size_t o = (size_t)env * g.env_stride + foff + c0;
     if (dbg) { dbg[((size_t)env * 4 + FIELD) * g.nc + c0] = G; return; }
-    const double gprev = gm[o];
+    // zeta^1 = 0: stage 1 must not read G^- at all (0 * NaN = NaN: a stale G^- of an env that blew up would survive
+    // its reset; the reference rebuilds the model on every reset, rbc_sim3D_api.jl:52-58).  Uniform branch.
+    const double gprev = (zet != 0.0) ? gm[o] : 0.0;
     nxt[o] = old + dt * (gam * G + zet * gprev);
     gm[o] = G;
     if (FIELD == 2 && k == nz - 1) nxt[(size_t)env * g.env_stride + 3 * (size_t)g.nc + c0 + nx * ny] = 0.0;   // top wall face
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
     const size_t ebase = (size_t)env * g.env_stride + foff;
     auto commit = [&](int k, double old, double G) {
         const size_t o = ebase + (size_t)k * pl + ij;
-        const double gprev = gm[o];
+        const double gprev = (zet != 0.0) ? gm[o] : 0.0;     // stage 1 never reads G^- (see k3_tendency)
         nxt[o] = old + dt * (gam * G + zet * gprev);
         gm[o] = G;
     };
@@ -529,7 +531,8 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     double nu5 = own(u, t.k0 + 3), nv5 = own(v, t.k0 + 3);
     double np0 = ph[(size_t)t.k0 * pl + col], npx = ph[(size_t)t.k0 * pl + t.j * nx + xi[2]], npy = ph[(size_t)t.k0 * pl + jm * nx + t.i];
-    double ngu = gm[eb + g.nc + (size_t)t.k0 * pl + col], ngv = gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col];
+    const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
+    double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = use_gm ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
         const bool more = (k + 1 < t.k0 + KT3);
 #pragma unroll
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
             tile_fetch(t, w + (size_t)min(k + 2, nz) * pl, pfw);
             nu5 = own(u, k + 4); nv5 = own(v, k + 4);
             np0 = ph[(size_t)(k + 1) * pl + col]; npx = ph[(size_t)(k + 1) * pl + t.j * nx + xi[2]]; npy = ph[(size_t)(k + 1) * pl + jm * nx + t.i];
-            ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col];
+            if (use_gm) { ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; }
         }
         const bool top = (k + 1 >= nz);
         const double wc = top ? 0.0 : L(IW, 0, 0);
@@ -657,7 +660,8 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     double nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
     double nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = cen(v, col, t.k0 + 2), nev = cen(v, colN, t.k0 + 2);
-    double ngw = gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col], ngb = gm[eb + (size_t)t.k0 * pl + col];
+    const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
+    double ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0, ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : 0.0;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
         const bool more = (k + 1 < t.k0 + KT3);
 #pragma unroll
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
             tile_fetch(t, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, b + (size_t)(k + 1) * pl, pfb);
             nw5 = fac(k + 4); nb5 = cen(b, col, k + 4);
             nau = cen(u, col, k + 3); neu = cen(u, colE, k + 3); nav = cen(v, col, k + 3); nev = cen(v, colN, k + 3);
-            ngw = gm[eb + 3 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; ngb = gm[eb + (size_t)(k + 1) * pl + col];
+            if (use_gm) { ngw = gm[eb + 3 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; ngb = gm[eb + (size_t)(k + 1) * pl + col]; }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- w at (i, j, z-face k); the wall face k = 0 never evolves ----

@@ -180,6 +180,11 @@ int rbc_device_count(void)
     return n;
 }
 
+int rbc_has_precision(int precision)
+{
+    return precision == RBC_PRECISION_F64 ? 1 : 0;
+}
+
 void rbc_default_config(rbc_config *c)
 {
     // gym registry defaults, src/rbc_gym/__init__.py:7-18, + constants rbc_sim2D_api.jl:28-38
@@ -195,6 +200,7 @@ void rbc_default_config(rbc_config *c)
     c->random_kick = 0.01;
     c->obs_nx = 48; c->obs_nz = 8;
     c->batch = 1; c->device = 0; c->write_state = 1;
+    c->precision = RBC_PRECISION_F64;
 }
 
 int rbc_create(const rbc_config *cfg, rbc_handle **out)
@@ -204,6 +210,8 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     if (cfg->abi_version != RBC_ABI_VERSION) return fail(RBC_ERR_INVALID, "rbc_config.abi_version mismatch");
     if (cfg->dim != 2 && cfg->dim != 3) return fail(RBC_ERR_INVALID, "dim must be 2 or 3");
     if (cfg->batch < 1) return fail(RBC_ERR_INVALID, "batch must be >= 1");
+    if (!rbc_has_precision(cfg->precision)) return fail(RBC_ERR_INVALID, "precision: this build carries RBC_PRECISION_F64 kernels only");
+    if (cfg->dim == 3 && cfg->precision != RBC_PRECISION_F64) return fail(RBC_ERR_INVALID, "precision: the 3D path is float64 only");
     if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
     if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
         return fail(RBC_ERR_INVALID, "ra, pr, dt_solver, dt_control must be positive");
@@ -658,6 +666,48 @@ int rbc_profile_read(rbc_handle *h, double *ms, int capacity)
     }
     h->ev_used = 0;
     return n;
+}
+
+int rbc_copy_ceiling(int device, size_t bytes, int iters, double *kernel_gbs, double *memcpy_gbs)
+{
+    if (iters < 1 || bytes < (size_t)1 << 20) return fail(RBC_ERR_INVALID, "rbc_copy_ceiling: need iters >= 1 and at least 1 MiB");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n16 = bytes / 16;
+    void *src = nullptr, *dst = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = RBC_OK;
+    auto bail = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == RBC_OK) rc = fail(RBC_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+    bail(hipMalloc(&src, n16 * 16), "hipMalloc");
+    if (rc == RBC_OK) bail(hipMalloc(&dst, n16 * 16), "hipMalloc");
+    if (rc == RBC_OK) bail(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    if (rc == RBC_OK) bail(hipEventCreate(&e0), "hipEventCreate");
+    if (rc == RBC_OK) bail(hipEventCreate(&e1), "hipEventCreate");
+    if (rc == RBC_OK) bail(hipMemsetAsync(src, 1, n16 * 16, st), "hipMemsetAsync");
+    for (int which = 0; which < 2 && rc == RBC_OK; ++which) {
+        double *out = which ? memcpy_gbs : kernel_gbs;
+        if (!out) continue;
+        for (int it = -2; it < iters && rc == RBC_OK; ++it) {     // two warm-up rounds
+            if (it == 0) bail(hipEventRecord(e0, st), "hipEventRecord");
+            if (which) bail(hipMemcpyAsync(dst, src, n16 * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+            else {
+                hipLaunchKernelGGL(rbc::copy16_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
+                bail(hipGetLastError(), "copy16_kernel");
+            }
+        }
+        if (rc == RBC_OK) bail(hipEventRecord(e1, st), "hipEventRecord");
+        if (rc == RBC_OK) bail(hipEventSynchronize(e1), "hipEventSynchronize");
+        float ms = 0.0f;
+        if (rc == RBC_OK) bail(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+        if (rc == RBC_OK) *out = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+    }
+    if (st) (void)hipStreamSynchronize(st);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    return rc;
 }
 
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h)

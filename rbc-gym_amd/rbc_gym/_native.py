@@ -16,7 +16,7 @@ ROOT = os.path.dirname(_PKG)                      # rbc-gym_amd/
 LIB_PATH = os.path.join(ROOT, "lib", "librbc_hip.so")
 
 RBC_OK, RBC_ERR_INVALID, RBC_ERR_DEVICE, RBC_ERR_NAN, RBC_ERR_NOT_INITIALIZED = range(5)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RbcConfig(C.Structure):
@@ -29,7 +29,9 @@ class RbcConfig(C.Structure):
                 ("dt_solver", C.c_double), ("dt_control", C.c_double),
                 ("random_kick", C.c_double),
                 ("obs_nx", C.c_int32), ("obs_nz", C.c_int32),
-                ("batch", C.c_int32), ("device", C.c_int32), ("write_state", C.c_int32)]
+                ("batch", C.c_int32), ("device", C.c_int32), ("write_state", C.c_int32), ("precision", C.c_int32)]
+
+PRECISIONS = {"f64": 0, "f32": 1}
 
 
 # every symbol include/rbc_hip.h declares: name -> (restype, argtypes)
@@ -39,6 +41,8 @@ SYMBOLS = {
     "rbc_abi_version": (C.c_int, []),
     "rbc_last_error": (C.c_char_p, []),
     "rbc_device_count": (C.c_int, []),
+    "rbc_has_precision": (C.c_int, [C.c_int]),
+    "rbc_copy_ceiling": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp, _dp]),
     "rbc_default_config": (None, [C.POINTER(RbcConfig)]),
     "rbc_create": (C.c_int, [C.POINTER(RbcConfig), C.POINTER(_vp)]),
     "rbc_destroy": (C.c_int, [_vp]),
@@ -167,6 +171,28 @@ def _ptr(a, typ):
     return a.ctypes.data_as(typ)
 
 
+def has_precision(name):
+    """does this build of librbc_hip.so carry kernels for "f64" / "f32"?"""
+    return bool(load_library().rbc_has_precision(PRECISIONS[name]))
+
+
+def copy_ceiling(device=0, nbytes=1 << 30, iters=10):
+    """on-box streaming-copy rate (GB/s, bytes read + written) by a 16-bytes-per-lane copy kernel and by hipMemcpyAsync D2D"""
+    lib = load_library()
+    k, m = C.c_double(), C.c_double()
+    rc = lib.rbc_copy_ceiling(int(device), int(nbytes), int(iters), C.byref(k), C.byref(m))
+    if rc != RBC_OK:
+        raise RbcError(rc, lib.rbc_last_error().decode())
+    return {"kernel_gbs": k.value, "memcpy_d2d_gbs": m.value, "bytes": int(nbytes), "iters": int(iters),
+            "note": "GB/s of bytes read + bytes written, device buffer to device buffer"}
+
+
+def torch_stream_handle(stream):
+    """value for rbc_set_stream that makes the sim run ON a torch stream: torch's default stream has handle 0, which the
+    C ABI reserves for "the handle's own stream", so it is passed as hipStreamLegacy (1) instead."""
+    return int(stream.cuda_stream) or 1
+
+
 class NativeSim:
     """A batch of B envs on one GPU.  Method names follow the reference's Julia API
     (rbc_sim2D_api.jl): initialize_simulation -> reset*, step_simulation -> step, get_state,
@@ -207,7 +233,8 @@ class NativeSim:
         if mask is None:
             return None, None
         m = np.ascontiguousarray(mask, dtype=np.uint8)
-        assert m.shape == (self.B,)
+        if m.shape != (self.B,):
+            raise ValueError(f"mask must have shape {(self.B,)}, got {m.shape}")
         return m, _ptr(m, _u8p)
 
     def reset(self, seeds, mask=None):
@@ -217,7 +244,10 @@ class NativeSim:
 
     def reset_from_arrays(self, b, u, w, mask=None):
         b = np.ascontiguousarray(b, np.float64); u = np.ascontiguousarray(u, np.float64); w = np.ascontiguousarray(w, np.float64)
-        assert b.shape == (self.B, self.nz, self.nx) and u.shape == b.shape and w.shape == (self.B, self.nz + 1, self.nx)
+        want = {"b": (self.B, self.nz, self.nx), "u": (self.B, self.nz, self.nx), "w": (self.B, self.nz + 1, self.nx)}
+        for name, a in (("b", b), ("u", u), ("w", w)):          # raw pointers go to memcpy: never trust the caller's shapes
+            if a.shape != want[name]:
+                raise ValueError(f"reset_from_arrays: {name} must have shape {want[name]} (batch, z, x), got {a.shape}")
         m, mp = self._mask(mask)
         self._check(self.lib.rbc_reset_from_arrays(self.h, mp, _ptr(b, _dp), _ptr(u, _dp), _ptr(w, _dp)))
 
@@ -232,7 +262,8 @@ class NativeSim:
             return
         lo = np.ascontiguousarray(min_vals, np.float64)
         hi = np.ascontiguousarray(max_vals, np.float64)
-        assert lo.shape == hi.shape and lo.ndim == 1
+        if lo.shape != hi.shape or lo.ndim != 1:
+            raise ValueError("set_obs_normalization: min_vals and max_vals must be 1-D and of equal length")
         self._check(self.lib.rbc_set_obs_normalization(self.h, _ptr(lo, _dp), _ptr(hi, _dp), int(lo.size), float(maxval), int(bool(clip))))
 
     # -- step_simulation ---------------------------------------------------------------------
@@ -262,7 +293,8 @@ class NativeSim:
     def get_state(self, nch=3, out=None):
         """float32 (B, nch, nz, nx); `out` may be a caller-owned array of that shape, e.g. from pinned_empty()"""
         o = np.empty((self.B, nch, self.nz, self.nx), np.float32) if out is None else out
-        assert o.shape == (self.B, nch, self.nz, self.nx) and o.dtype == np.float32 and o.flags.c_contiguous
+        if o.shape != (self.B, nch, self.nz, self.nx) or o.dtype != np.float32 or not o.flags.c_contiguous:
+            raise ValueError(f"get_state: out must be a C-contiguous float32 array of shape {(self.B, nch, self.nz, self.nx)}")
         self._check(self.lib.rbc_get_state(self.h, _ptr(o, _fp), nch))
         return o
 
@@ -364,6 +396,8 @@ class NativeSim3D:
         if mask is None:
             return None
         self._m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if self._m.shape != (self.B,):
+            raise ValueError(f"mask must have shape {(self.B,)}, got {self._m.shape}")
         return _ptr(self._m, _u8p)
 
     def reset(self, seeds, mask=None):
@@ -372,7 +406,10 @@ class NativeSim3D:
 
     def reset_from_arrays(self, b, u, v, w, mask=None):
         a = [np.ascontiguousarray(x, np.float64) for x in (b, u, v, w)]
-        assert a[0].shape == (self.B, self.nz, self.ny, self.nx) and a[3].shape == (self.B, self.nz + 1, self.ny, self.nx)
+        cen, fac = (self.B, self.nz, self.ny, self.nx), (self.B, self.nz + 1, self.ny, self.nx)
+        for name, x, want in (("b", a[0], cen), ("u", a[1], cen), ("v", a[2], cen), ("w", a[3], fac)):
+            if x.shape != want:
+                raise ValueError(f"reset_from_arrays: {name} must have shape {want} (batch, z, y, x), got {x.shape}")
         self._check(self.lib.rbc_reset_from_arrays3(self.h, self._mask(mask), *[_ptr(x, _dp) for x in a]))
 
     def set_rayleigh(self, ra):

@@ -31,6 +31,30 @@ def pick_checkpoint_episode(num_episodes, seed):
     return int(np.random.default_rng(int(seed) % (2**63)).integers(0, num_episodes))
 
 
+def checkpoint_index(checkpoint_idx, num_episodes, seed):
+    """0-based row of the episode to load.  `checkpoint_idx` is the reference's kwarg and keeps its meaning: it goes
+    straight into Julia's `read(h5, "b")[idx, :, :, :]` (rbc_sim3D.jl:186-192), i.e. it is 1-BASED (eval_sarl.py:45 uses
+    checkpoint_idx=1 for the first episode); 0 or > num_episodes is Julia's BoundsError, an IndexError here.  None =
+    the seeded draw that stands in for `rand(1:n)`."""
+    if checkpoint_idx is None:
+        return pick_checkpoint_episode(num_episodes, seed)
+    idx = int(checkpoint_idx)
+    if not 1 <= idx <= int(num_episodes):
+        raise IndexError(f"checkpoint_idx={checkpoint_idx} out of range: episodes are numbered 1..{int(num_episodes)} "
+                         "(1-based, as in the reference's Julia reader)")
+    return idx - 1
+
+
+def check_checkpoint_grid(path, data, fields, state_shape):
+    """the arrays of a checkpoint go to the device as raw pointers: refuse a file written on another grid"""
+    cen = tuple(int(n) for n in state_shape)
+    for f in fields:
+        want = (cen[0] + 1,) + cen[1:] if f == "w" else cen
+        got = tuple(data[f].shape[1:])
+        if got != want:
+            raise ValueError(f"{path}: dataset {f!r} has grid {got}, this env needs {want} (state_shape={list(cen)})")
+
+
 def box_stack(shape, bounds):
     """Box over `len(bounds)` channels of `shape`, channel c bounded by bounds[c] = (low, high)."""
     shape = tuple(int(s) for s in shape)
@@ -112,9 +136,8 @@ class NativeEnvBase(gym.Env):
         missing = [f for f in self._fields if f not in data]
         if missing:
             raise ValueError(f"{path}: checkpoint lacks dataset(s) {missing} needed by this env")
-        idx = getattr(self, "checkpoint_idx", None)
-        if idx is None:
-            idx = pick_checkpoint_episode(data["num_episodes"], seed)
+        idx = checkpoint_index(getattr(self, "checkpoint_idx", None), data["num_episodes"], seed)
+        check_checkpoint_grid(path, data, self._fields, self.state_shape)
         return [data[f][idx:idx + 1] for f in self._fields]
 
     def reset(self, seed=None, options=None):

@@ -15,7 +15,8 @@ import numpy as np
 from ._gym import gym
 from . import _native
 from .checkpoint import read_checkpoint
-from .envs.rbc2D import build_spaces, pick_checkpoint_episode, sim_kwargs
+from .envs._common import check_checkpoint_grid, checkpoint_index
+from .envs.rbc2D import build_spaces, sim_kwargs
 
 
 class DeviceArray:
@@ -62,8 +63,12 @@ class _BatchedEnv(gym.vector.VectorEnv):
             if self._ckpt is None:
                 self._ckpt = read_checkpoint(path)
             ck = self._ckpt
-            fixed = getattr(self, "checkpoint_idx", None)
-            idx = np.array([pick_checkpoint_episode(ck["num_episodes"], s) if fixed is None else fixed for s in seeds])
+            missing = [f for f in self._fields if f not in ck]
+            if missing:
+                raise ValueError(f"{path}: checkpoint lacks dataset(s) {missing} needed by this env")
+            check_checkpoint_grid(path, ck, self._fields, self.state_shape)
+            fixed = getattr(self, "checkpoint_idx", None)                 # 1-based, like the reference's (rbc_sim3D.jl:186-192)
+            idx = np.array([checkpoint_index(fixed, ck["num_episodes"], s) for s in seeds])
             self.sim.reset_from_arrays(*[ck[f][idx] for f in self._fields], mask=mask)
         else:
             self.sim.reset(np.asarray(seeds, dtype=np.uint64), mask=mask)

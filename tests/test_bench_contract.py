@@ -40,3 +40,52 @@ def test_bench_line_3d_small_batch():
     d = _run("--dim", "3", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline")
     assert REQUIRED <= set(d) and d["nan_envs"] == 0 and d["value"] > 0
     assert abs(d["roofline"]["algorithmic_bytes_per_launch"] - 4 * 13 * 10 * 4 * 73728 * 8) < 1
+
+
+def test_gpus_without_launcher_never_prints_a_one_gpu_line():
+    """`python bench.py --gpus 8` without torchrun must either start its own 8 ranks or fail: it may never print an
+    n_gpus=1 line with rc 0.  In this container there is no GPU, so the self-launcher refuses (fewer devices than asked)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert out.returncode != 0 and not lines, (out.returncode, out.stdout[-500:])
+        assert "--gpus 8" in out.stderr
+    else:                                              # a full node: the self-launched ranks print the 8-GPU line
+        assert out.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_self_launched_two_rank_rehearsal_on_one_gpu():
+    """`--gpus 2` with no launcher: bench.py starts its own two ranks (gloo rehearsal: both share the one GPU of a test
+    box) and rank 0 prints one n_gpus=2 line whose value counts the envs of both shards."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+                          "--warmup", "1", "--batch", "32"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["cpu_baseline"] is None and d["nan_envs"] == 0
+    assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_extra_keys_are_measured_in_the_same_run():
+    d = _run("--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline")
+    x = d["extra"]
+    assert "error" not in x, x
+    assert x["copy_ceiling"]["kernel_gbs"] > 500 and x["copy_ceiling"]["memcpy_d2d_gbs"] > 500
+    assert x["gym_api_env_steps_per_s"]["no_info_state"] > 0 and x["gym_api_env_steps_per_s"]["pinned_info_state"] > 0
+    c4 = x["config4_3d"]
+    assert c4["nan_envs"] == 0 and c4["value"] > 0 and "32x48x48" in c4["config"]["workload"]
+    assert d["roofline"]["on_box_copy_gbs"] == x["copy_ceiling"]["kernel_gbs"]

@@ -105,7 +105,7 @@ def test_generate_3d_checkpoints_and_reset_from_them(tmp_path):
     div = ((np.roll(r["u"], -1, axis=3) - r["u"]) / dx + (np.roll(r["v"], -1, axis=2) - r["v"]) / dy
            + (r["w"][:, 1:] - r["w"][:, :-1]) / (2.0 / 8))
     assert np.abs(div).max() < 1e-11
-    env = gym.make("rbc_gym/RayleighBenardConvection3D-v0", state_shape=(8, 16, 16), rayleigh_number=2500, checkpoint=p, checkpoint_idx=2)
-    obs, _ = env.reset(seed=0)
+    env = gym.make("rbc_gym/RayleighBenardConvection3D-v0", state_shape=(8, 16, 16), rayleigh_number=2500, checkpoint=p, checkpoint_idx=3)
+    obs, _ = env.reset(seed=0)       # checkpoint_idx is 1-based like the reference's Julia reader (rbc_sim3D.jl:186-192): 3 = the last episode
     assert np.array_equal(obs[0], r["b"][2].astype(np.float32)) and np.array_equal(obs[3], r["w"][2][:8].astype(np.float32))
     env.close()

@@ -131,10 +131,12 @@ def test_device_views_are_zero_copy_torch_tensors(gym):
     venv.close()
 
 
-def test_full_batch_properties():
-    """BASELINE.json configs[1] size (B=1024): properties that need no oracle run --
-    exact discrete incompressibility, bitwise run-to-run determinism, independence from the batch
-    composition, and x-translation equivariance by one heater segment (8 cells)."""
+@pytest.mark.parametrize("dt_control", [1.5, 0.3], ids=["full-interval-50-substeps", "10-substeps"])
+def test_full_batch_properties(dt_control):
+    """BASELINE.json configs[1] size (B=1024) at the control interval the bench times (heater_duration 1.5 = 50 RK3
+    substeps) and a short one: properties that need no oracle run -- exact discrete incompressibility, bitwise
+    run-to-run determinism, independence from the batch composition, and x-translation equivariance by one heater
+    segment (8 cells)."""
     from rbc_gym import _native
     B = 1024
     rng = np.random.default_rng(7)
@@ -142,7 +144,7 @@ def test_full_batch_properties():
     seeds = np.arange(B, dtype=np.uint64) + 1234
 
     def run(actions, b0=None):
-        sim = _native.NativeSim(batch=B, dt_control=0.3)
+        sim = _native.NativeSim(batch=B, dt_control=dt_control)
         if b0 is None:
             sim.reset(seeds)
         else:
@@ -226,10 +228,19 @@ def test_3d_env_contract(gym, tmp_path):
     for name in ("3D_ckpt_ra2500.h5", "c3.npz"):
         ck = str(tmp_path / name)
         write_checkpoint(ck, f[0], f[1], f[3], v=f[2], start_seed=9)
-        env2 = gym.make(ID3, state_shape=(8, 16, 16), checkpoint=ck, checkpoint_idx=0)
+        env2 = gym.make(ID3, state_shape=(8, 16, 16), checkpoint=ck, checkpoint_idx=1)      # 1-based (rbc_sim3D.jl:186-192; eval_sarl.py:45)
         o3, _ = env2.reset(seed=1)
         assert np.array_equal(o3[0], f[0][0].astype(np.float32)) and np.array_equal(o3[2], f[2][0].astype(np.float32))
         env2.close()
+        for bad in (0, 2):                                      # Julia: BoundsError for 0 and for num_episodes + 1
+            env3 = gym.make(ID3, state_shape=(8, 16, 16), checkpoint=ck, checkpoint_idx=bad)
+            with pytest.raises(IndexError):
+                env3.reset(seed=1)
+            env3.close()
+    wrong = gym.make(ID3, state_shape=(8, 16, 32), checkpoint=ck, checkpoint_idx=1)          # file written on another grid
+    with pytest.raises(ValueError):
+        wrong.reset(seed=1)
+    wrong.close()
 
 
 def test_fused_observation_normalisation_is_bit_identical_to_the_numpy_wrapper(gym):

@@ -127,6 +127,46 @@ def test_env_step_matches_oracle(native, oracle, ckpt_ra1e4, ckpt_ra1e5, dt_cont
     assert np.allclose(t, 2 * dt_control) and np.all(s == 3)
 
 
+@pytest.mark.parametrize("ra", [1e6, 1e7])
+def test_developed_high_rayleigh_state_matches_oracle(native, oracle, ra):
+    """BASELINE.json configs[3]'s stiff end: field-level parity on a DEVELOPED state at Ra=1e6 (advective CFL ~ 1.1,
+    upwind signs flip everywhere) and Ra=1e7 (the most under-resolved case of the reference's sweep).  The GPU runs
+    from rest to t = 150 under random actions, the fields go to both sides through reset_from_arrays; then tendencies
+    (1e-11) and one full control interval of 50 substeps (1e-8 rel-L2: chaotic amplification of round-off, still 100x
+    inside north_star's 1e-6)."""
+    B = 2
+    gen = native.NativeSim(batch=B, ra=ra)
+    gen.reset(np.array([31, 32], dtype=np.uint64))
+    rng = np.random.default_rng(9)
+    for n in range(100):
+        assert gen.step(rng.uniform(-1, 1, (B, 12)).astype(np.float32)), f"NaN at step {n}"
+    b0, u0, w0 = gen.get_fields()
+    gen.close()
+    assert np.abs(w0).max() > 0.3                                     # turbulent convection, not the conductive state
+    sim = native.NativeSim(batch=B, ra=ra)
+    sim.reset_from_arrays(b0, u0, w0)
+    act = rng.uniform(-1, 1, (B, 12)).astype(np.float32)
+    g = sim.debug_tendencies(act)
+    orcs = []
+    for e in range(B):
+        o = oracle.OracleSim(ra=ra)
+        o.reset_from_arrays(b0[e], u0[e], w0[e])
+        o.set_action(act[e]); o.update_state()
+        go = o.tendencies()
+        for f in "buw":
+            assert np.abs(g[f][e] - go[f]).max() < 1e-11 * max(np.abs(go[f]).max(), 1.0), f
+        orcs.append(o)
+    assert sim.step(act)
+    b, u, w = sim.get_fields()
+    nus, nuo = sim.get_nusselt()
+    for e, o in enumerate(orcs):
+        assert o.step(act[e])
+        ob, ou, ow = o.fields()
+        assert rel_l2(b[e], ob) < 1e-8 and rel_l2(u[e], ou) < 1e-8 and rel_l2(w[e], ow) < 1e-8
+        assert abs(nus[e] - o.nusselt(True)) < 1e-6 * abs(o.nusselt(True))
+        assert abs(nuo[e] - o.nusselt(False)) < 1e-6 * abs(o.nusselt(False))
+
+
 def test_pressure_channels(native, oracle, ckpt_ra1e4):
     """channel 5 (pNHS) is the last stage's projection potential with zero mean: compare with
     the oracle after one env step (looser: phi is div/dt-amplified round-off plus physics)."""

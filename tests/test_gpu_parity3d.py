@@ -118,6 +118,85 @@ def test_masked_reset_batch_independence_and_nan(native, o3):
     assert list(sim.get_flags()) == [0, 1, 0]
 
 
+def test_nan_env_recovers_after_masked_reset(native, o3):
+    """An env that blew up must come back clean from a masked reset (the vector env's autoreset path tolerates a
+    flagged env that is re-initialised in the same step, vector.py): its stale G^- may hold NaN, and stage 1 of the
+    next substep multiplies G^- by zeta^1 = 0 -- it must not read it at all.  The reference rebuilds the whole model on
+    reset (rbc_sim3D_api.jl:52-58)."""
+    ic = _developed_state(o3, 43)
+    B = 2
+    arrs = [np.stack([x] * B) for x in ic]
+    act = np.random.default_rng(8).uniform(-1, 1, (B, 8, 8)).astype(np.float32)
+    act[1] = act[0]
+    sim = native.NativeSim3D(batch=B, shape=SHAPE, domain=DOMAIN, ra=5000.0, dt_control=0.02)
+    bad = [a.copy() for a in arrs]
+    bad[1][0, 2, 5, 7] = np.nan                                     # u of env 0
+    sim.reset_from_arrays(*bad)
+    assert not sim.step(act)                                         # NaN spreads into env 0's state AND its G^-
+    assert list(sim.get_flags()) == [1, 0]
+    sim.reset_from_arrays(*arrs, mask=[1, 0])                        # masked reset of the broken env only
+    sim.reset_from_arrays(*arrs, mask=[0, 1])                        # and bring env 1 back to the same state
+    assert sim.step(act)
+    f = sim.get_fields()
+    assert list(sim.get_flags()) == [0, 0]
+    for q in range(4):
+        assert np.isfinite(f[q]).all()
+        assert np.array_equal(f[q][0], f[q][1])                      # the recovered env equals one that never broke
+    # same through a random reset
+    sim.reset_from_arrays(*bad)
+    assert not sim.step(act)
+    sim.reset(np.array([5, 5], dtype=np.uint64))
+    assert sim.step(act)
+    g = sim.get_fields()
+    for q in range(4):
+        assert np.isfinite(g[q]).all() and np.array_equal(g[q][0], g[q][1])
+
+
+def test_config4_shape_matches_oracle(native, o3):
+    """BASELINE.json configs[4] exactly: 32x48x48, Ra=1e4, heater_duration 0.125, dt_solver 0.01 (x t_ff=4: 12 x 0.04 +
+    0.02 = 13 RK3 substeps), B=2, from a DEVELOPED convecting state (the GPU runs from a kicked start under random actions
+    until Nu > 1.5; the fields then go to both sides through reset_from_arrays).  48 = 6 x 8 takes the register-blocked
+    FFT in x AND y, ny % 16 == 0 the 16x4 tiles, nz = 32 the packed z solve.  Tendencies 1e-11, one env-step 1e-10."""
+    shape, ra = (32, 48, 48), 1e4
+    B = 2
+    gen = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, random_kick=0.1)
+    gen.reset(np.array([11, 12], dtype=np.uint64))
+    rng = np.random.default_rng(4)
+    nu = None
+    for n in range(400):
+        assert gen.step(rng.uniform(-1, 1, (B, 8, 8)).astype(np.float32))
+        nu = gen.get_nusselt()
+        if n >= 60 and np.all(nu > 1.5):
+            break
+    assert np.all(nu > 1.5), nu                                       # convection has set in: every operator term is active
+    ics = gen.get_fields()
+    gen.close()
+    assert np.abs(ics[3]).max() > 0.05
+    sim = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01)
+    sim.reset_from_arrays(*ics)
+    act = rng.uniform(-1, 1, (B, 8, 8)).astype(np.float32)
+    g = sim.debug_tendencies(act)
+    orcs = []
+    for e in range(B):
+        o = o3.Oracle3D(ra=ra, shape=shape, dt_control=0.125, dt_solver=0.01)
+        o.reset_from_arrays(*[x[e] for x in ics])
+        o.set_action(act[e]); o.update_state()
+        go = o.tendencies()
+        for f in "uvwb":
+            assert np.abs(g[f][e] - go[f]).max() < 1e-11 * max(np.abs(go[f]).max(), 1.0), f
+        orcs.append(o)
+    assert sim.step(act)
+    fields, nus, st = sim.get_fields(), sim.get_nusselt(), sim.get_state()
+    for e, o in enumerate(orcs):
+        assert o.step(act[e])
+        for x, y in zip(fields, o.fields()):
+            assert rel_l2(x[e], y) < 1e-10
+        assert abs(nus[e] - o.nusselt()) < 1e-9 * abs(o.nusselt())
+        assert np.allclose(st[e], o.state(), rtol=1e-5, atol=1e-6)
+    t, s = sim.get_info()
+    assert np.allclose(t, 0.5) and np.all(s == 2)
+
+
 def test_fast_fft_sizes(native, o3):
     """48 = 6x8 and 64 = 8x8 take the register-blocked slab FFT (dft6 / dft8 x dft8); the other tests
     run 32 = 4x8 and the generic 24 = 4x6 path."""
