@@ -102,6 +102,16 @@ int  rbc_set_rayleigh(rbc_handle *h, const double *ra);
    nch = 0 switches the transform off.  Takes effect from the next reset/step; rbc_get_state is never transformed. */
 int  rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip);
 
+/* RBCRewardShaping.compute_cell_distances (wrappers/rbc_reward_shaping.py:85-140) on the device, for every env of a dim=2
+   handle created with write_state=1: the largest periodic distance between two up-welling plumes (peaks of the float32
+   vertical-velocity channel on the row nz/2 - 1 that reach `height`, the reference uses 0.001), 0 if the signal stays
+   positive between them; domain length = cfg.lx.  out[B] float64 on the host; bit-identical to the numpy wrapper.
+   rbc_dev_cell_dist: the device buffer the last call filled (NULL before the first call).
+   rbc_debug_cell_distances: the same kernel on caller-provided host signals uy[B][nx] (parity tests).                  */
+int   rbc_get_cell_distances(rbc_handle *h, double height, double *out);
+void *rbc_dev_cell_dist(rbc_handle *h);
+int   rbc_debug_cell_distances(int device, const float *uy, int B, int nx, double lx, double height, double *out);
+
 /* Page-locked host buffers for the rbc_get_* outputs: a pageable destination limits the float32 state copy of 1024
    envs (75 MB) to the driver's staging rate, a pinned one takes it at PCIe speed.  Plain helpers over hipHostMalloc /
    hipHostFree; any rbc_get_* accepts either kind of pointer.                                                        */

@@ -1110,11 +1110,73 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #endif
 }
 
-// streaming-copy kernel for rbc_copy_ceiling: 16 bytes per lane, grid-stride, 4096 workgroups of 256 threads
-__global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+// RBCRewardShaping.compute_cell_distances (wrappers/rbc_reward_shaping.py:85-140) for a batch of mid-line signals, one
+// wave64 per env: uy[env * stride + i], i < nx <= 256 (the float32 w channel of the state at row nz/2 - 1).
+//   peaks = scipy.signal.find_peaks(uy, height): strict rise before, strict fall after, a flat top counts once at its
+//           middle sample (rounded down), the end samples never count; kept if uy[peak] >= height (compared in float32,
+//           as numpy compares a float32 array with a python float);
+//   for every pair i < j of peaks: direct = |x_j - x_i| with x_k = k * (lx / nx)  (np.linspace(0, lx, nx, endpoint=False)),
+//           around = lx - direct, d = min(direct, around); d = 0 if the signal stays positive between the two peaks the
+//           short way round ([i, j) if direct < around, else [j, nx) and [0, i));  result = max d (0 with fewer than 2 peaks).
+// Same float32 comparisons and float64 arithmetic as the numpy code: results are bit-identical (tests/test_env_gpu.py).
+__global__ __launch_bounds__(64) void cell_distance_kernel(const float *__restrict__ uy, size_t stride, int nx, double lx, float height,
+                                                           double *__restrict__ out)
 {
+    __shared__ float x[256];
+    __shared__ int cnt[257];        // cnt[i] = number of samples j < i with uy[j] <= 0 (or NaN)
+    __shared__ int peaks[128];
+    __shared__ int npk;
+    const int env = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < nx; i += 64) x[i] = uy[(size_t)env * stride + i];
+    if (lane == 0) npk = 0;
+    __syncthreads();
+    if (lane == 0) {
+        int c = 0;
+        for (int i = 0; i < nx; ++i) { cnt[i] = c; c += (x[i] > 0.0f) ? 0 : 1; }
+        cnt[nx] = c;
+    }
+    for (int i = lane + 1; i < nx - 1; i += 64) {
+        if (x[i - 1] < x[i]) {                                   // a rise: i starts a (possibly flat) top
+            int j = i + 1;
+            while (j < nx - 1 && x[j] == x[i]) ++j;
+            if (x[j] < x[i]) {
+                const int p = (i + j - 1) / 2;
+                if (x[p] >= height) peaks[atomicAdd(&npk, 1)] = p;
+            }
+        }
+    }
+    __syncthreads();
+    const int P = npk;
+    const double step = lx / (double)nx;
+    double best = 0.0;
+    for (int a = 0; a < P; ++a)
+        for (int b = a + 1 + lane; b < P; b += 64) {
+            const int i = min(peaks[a], peaks[b]), j = max(peaks[a], peaks[b]);
+            const double direct = fabs((double)j * step - (double)i * step), around = lx - direct;
+            double d = (around < direct) ? around : direct;
+            if (direct < around) { if (cnt[j] - cnt[i] == 0) d = 0.0; }
+            else if (cnt[nx] - cnt[j] == 0 && cnt[i] == 0) d = 0.0;
+            best = fmax(best, d);
+        }
+    for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off, 64));
+    if (lane == 0) out[env] = best;
+}
+
+// streaming-copy kernel for rbc_copy_ceiling: 16 bytes per lane, grid-stride, 4096 workgroups of 256 threads
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ src_, uint4 *__restrict__ dst_, size_t n)
+{
+    const u32x4 *__restrict__ src = reinterpret_cast<const u32x4 *>(src_);
+    u32x4 *__restrict__ dst = reinterpret_cast<u32x4 *>(dst_);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {                 // four independent 16-byte loads in flight per lane
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 }  // namespace rbc

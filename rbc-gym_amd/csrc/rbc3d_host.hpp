@@ -128,7 +128,10 @@ int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
         hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
         hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
         hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
-        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
+        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi, buf, dts, mask);
+        hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - g.nx * g.ny), 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
+        HIP3(hipGetLastError());
+        return RBC_OK;
     } else {
         hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
         hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, s->spec, s->tab, B);
@@ -160,22 +163,25 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
         const double d = (n == nsub - 1) ? dt_last : dt;
         for (int ph = 0; ph < 3; ++ph) {
             double *cur = s->st[s->cur], *nxt = s->st[s->cur ^ 1];
-            hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
             auto tiles_fit = [&](int ty, int kt, int maxt) {
                 const int thr = g.nx * ty;
                 return !h->no_tile && g.nz % kt == 0 && g.ny % ty == 0 && thr <= maxt && thr % 64 == 0 && g.nx <= rbc3::NXP3 &&
                        (ty + 6) * g.nx <= 2 * thr;
             };
+            const int store_g = (ph != 2);                     // the last stage's tendencies are never read again (zeta^1 = 0)
+            const bool tiled = tiles_fit(16, 4, 768) || tiles_fit(8, 8, 512);
+            if (!tiled)                                        // the fallback kernels use the hydrostatic split (pHY' column scan)
+                hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
             if (tiles_fit(16, 4, 768)) {                       // LDS-tiled kernels: planes staged once per level
                 const dim3 gt((unsigned)((size_t)B * (g.ny / 16) * (g.nz / 4))), bt(g.nx * 16);
                 const size_t pb = (size_t)(16 + 6) * rbc3::NXP3 * sizeof(double);
-                hipLaunchKernelGGL((rbc3::k3_tile_uv<16, 4, 2, 768, 3>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->phy, h->d_ra, d, gam[ph], zet[ph]);
-                hipLaunchKernelGGL((rbc3::k3_tile_wb<16, 4, 2, 768, 3>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph]);
+                hipLaunchKernelGGL((rbc3::k3_tile_uv<16, 4, 2, 768, 3>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, h->d_ra, d, gam[ph], zet[ph], store_g);
+                hipLaunchKernelGGL((rbc3::k3_tile_wb<16, 4, 2, 768, 3>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
             } else if (tiles_fit(8, 8, 512)) {
                 const dim3 gt((unsigned)((size_t)B * (g.ny / 8) * (g.nz / 8))), bt(g.nx * 8);
                 const size_t pb = (size_t)(8 + 6) * rbc3::NXP3 * sizeof(double);
-                hipLaunchKernelGGL((rbc3::k3_tile_uv<8, 8, 2, 512, 2>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->phy, h->d_ra, d, gam[ph], zet[ph]);
-                hipLaunchKernelGGL((rbc3::k3_tile_wb<8, 8, 2, 512, 2>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph]);
+                hipLaunchKernelGGL((rbc3::k3_tile_uv<8, 8, 2, 512, 2>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, h->d_ra, d, gam[ph], zet[ph], store_g);
+                hipLaunchKernelGGL((rbc3::k3_tile_wb<8, 8, 2, 512, 2>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
             } else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
                 const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
                 hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);

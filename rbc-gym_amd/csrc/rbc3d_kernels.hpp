@@ -433,7 +433,15 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
 // once in LDS by the whole group -- fetched into registers one level ahead so the loads fly under the arithmetic --
 // and every cross-column stencil value is an LDS read; each thread keeps its own column's z windows and the
 // carried face fluxes in registers.  Two kernels: (u, v) share the planes u, v, w(k+1); (w, b) the planes w, b.
-// About 24 global loads per cell for all four fields (marching kernels: ~90, cell-per-thread: ~380).
+// About 21 global loads per cell for all four fields (marching kernels: ~90, cell-per-thread: ~380).
+// Buoyancy: Oceananigans splits off a hydrostatic pressure anomaly pHY' (d pHY'/dz = b at the w faces) and puts
+// -grad_h pHY' into G_u, G_v and nothing into G_w ([OC] update_hydrostatic_pressure.jl; the z-marching and cell-per-thread
+// kernels above and the oracle do exactly that).  The tiled kernels use the un-split form instead -- +b_face in G_w, no pHY'
+// anywhere: the two tendency fields differ by the discrete gradient of pHY' with its wall-normal components dropped, which
+// is exactly what the pressure projection removes (its potential becomes phi - pHY'), so U after every stage is the same to
+// round-off (tests/test_gpu_parity3d.py holds it to the oracle at 1e-11) while the column scan kernel, its 3 loads per
+// cell in (u, v) and its store disappear from the stage.  store_g = 0 in the last stage of a substep, whose tendencies
+// are never read again (zeta^1 = 0).
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
 
 template <int TY3, int KT3>
@@ -477,8 +485,8 @@ __device__ __forceinline__ void tile_store(const TG &t, double *dst, const doubl
 // 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
 // (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
 template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
-__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *cur, double *nxt, double *gm, const double *phy,
-                                                  const double *nu_kappa, double dt, double gam, double zet)
+__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *cur, double *nxt, double *gm,
+                                                  const double *nu_kappa, double dt, double gam, double zet, int store_g)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
     const TileGeo<TY3, KT3> t(g);
@@ -488,13 +496,11 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
     constexpr int IU = 0, IV = PLANE3, IW = 2 * PLANE3;
     const double *sb = cur + (size_t)t.env * g.env_stride;
     const double *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
-    const double *ph = phy + (size_t)t.env * g.nc;
     const double nu = nu_kappa[2 * t.env];
     const double rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
     int xi[7];
     wrap7(t.i, nx, xi);
     const int col = t.j * nx + t.i;                               // own column inside a level
-    const int jm = (t.j == 0) ? t.ny - 1 : t.j - 1;
     // one LDS address per x offset; the plane and the y offset are immediates of the ds_read
     const double *xb[7];
 #pragma unroll
@@ -530,7 +536,6 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
     const size_t eb = (size_t)t.env * g.env_stride;
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     double nu5 = own(u, t.k0 + 3), nv5 = own(v, t.k0 + 3);
-    double np0 = ph[(size_t)t.k0 * pl + col], npx = ph[(size_t)t.k0 * pl + t.j * nx + xi[2]], npy = ph[(size_t)t.k0 * pl + jm * nx + t.i];
     const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
     double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = use_gm ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
@@ -538,12 +543,11 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
 #pragma unroll
         for (int q = 0; q < 5; ++q) { winu[q] = winu[q + 1]; winv[q] = winv[q + 1]; }
         winu[5] = nu5; winv[5] = nv5;
-        const double p0 = np0, pxm = npx, pym = npy, gpu_ = ngu, gpv_ = ngv;
+        const double gpu_ = ngu, gpv_ = ngv;
         if (more) {                                               // next level's planes and operands fly under this level's arithmetic
             tile_fetch(t, u + (size_t)(k + 1) * pl, pfu); tile_fetch(t, v + (size_t)(k + 1) * pl, pfv);
             tile_fetch(t, w + (size_t)min(k + 2, nz) * pl, pfw);
             nu5 = own(u, k + 4); nv5 = own(v, k + 4);
-            np0 = ph[(size_t)(k + 1) * pl + col]; npx = ph[(size_t)(k + 1) * pl + t.j * nx + xi[2]]; npy = ph[(size_t)(k + 1) * pl + jm * nx + t.i];
             if (use_gm) { ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; }
         }
         const bool top = (k + 1 >= nz);
@@ -570,10 +574,10 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
             const double vis = nu * (2.0 * ((q7[4] - f0) - (f0 - q7[2])) * rdx * rdx
                                      + (((c7[4] - f0) * rdy + (on_c - on_m) * rdx) - ((f0 - c7[2]) * rdy + (os_c - os_m) * rdx)) * rdy
                                      + (((fup - f0) * rdz + dwt * rdx) - ((f0 - fdnu) * rdz + dwbu * rdx)) * rdz);
-            const double G = vis - adv - (p0 - pxm) * rdx;
+            const double G = vis - adv;                          // buoyancy sits in G_w (see the header comment of these kernels)
             const size_t o = eb + g.nc + (size_t)k * pl + col;
             nxt[o] = f0 + dt * (gam * G + zet * gpu_);
-            gm[o] = G;
+            if (store_g) gm[o] = G;
             fbu = ft; dwbu = dwt; fdnu = f0;
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the two sections' live ranges apart
@@ -598,10 +602,10 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
             const double vis = nu * (2.0 * ((q7[4] - f0) - (f0 - q7[2])) * rdy * rdy
                                      + (((c7[4] - f0) * rdx + (on_c - on_m) * rdy) - ((f0 - c7[2]) * rdx + (os_c - os_m) * rdy)) * rdx
                                      + (((fup - f0) * rdz + dwt * rdy) - ((f0 - fdnv) * rdz + dwbv * rdy)) * rdz);
-            const double G = vis - adv - (p0 - pym) * rdy;
+            const double G = vis - adv;
             const size_t o = eb + 2 * (size_t)g.nc + (size_t)k * pl + col;
             nxt[o] = f0 + dt * (gam * G + zet * gpv_);
-            gm[o] = G;
+            if (store_g) gm[o] = G;
             fbv = ft; dwbv = dwt; fdnv = f0;
         }
         if (more) {
@@ -615,7 +619,7 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
 // (w, b): same launch shape, LDS = 2 planes (w and b at the current level)
 template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
 __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
-                                                  const double *nu_kappa, double dt, double gam, double zet)
+                                                  const double *nu_kappa, double dt, double gam, double zet, int store_g)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
     const TileGeo<TY3, KT3> t(g);
@@ -696,10 +700,10 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
                 const double vis = nu * ((((eu[3] - eu[2]) * rdz + (q7[4] - w0) * rdx) - ((au[3] - au[2]) * rdz + (w0 - q7[2]) * rdx)) * rdx
                                          + (((ev[3] - ev[2]) * rdz + (c7[4] - w0) * rdy) - ((av[3] - av[2]) * rdz + (w0 - c7[2]) * rdy)) * rdy
                                          + 2.0 * ((winw[3] - w0) - (w0 - winw[1])) * rdz * rdz);
-                const double G = vis - adv;
+                const double G = vis - adv + 0.5 * (winb[1] + winb[2]);      // + b at the face: the un-split buoyancy term
                 nxt[o] = w0 + dt * (gam * G + zet * gpw_);
-                gm[o] = G;
-            } else { nxt[o] = 0.0; gm[o] = 0.0; }
+                if (store_g) gm[o] = G;
+            } else { nxt[o] = 0.0; if (store_g) gm[o] = 0.0; }
             fbw = ft;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
             const double G = dif - adv;
             const size_t o = eb + (size_t)k * pl + col;
             nxt[o] = b0 + dt * (gam * G + zet * gpb_);
-            gm[o] = G;
+            if (store_g) gm[o] = G;
             fbb = ft; bdn = b0;
         }
         if (more) {
@@ -1070,12 +1074,15 @@ __global__ void k3_thomas_pair_bwd(Geo3 g, double2 *spec, const double2 *jct, co
     }
 }
 
-// inverse 2D FFT of a packed slab pair -> phi of slab k (real part) and of slab nz-1-k (imaginary part)
-__global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
+// inverse 2D FFT of a packed slab pair -> phi of slab k (real part) and of slab nz-1-k (imaginary part), and, with both
+// potentials of the slab still in LDS, the horizontal half of pressure_correct_velocities!: u -= dts dphi/dx, v -= dts dphi/dy
+// on the two slabs (st != nullptr).  The vertical half needs phi of the slab below: k3_correct_w.
+__global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *phi, double *st, double dts, const uint8_t *mask)
 {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
     const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2;
     const int env = blockIdx.x / half, k = blockIdx.x - env * half;
+    if (mask && !mask[env]) return;                               // masked reset: this env is not being projected
     double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
     for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
     for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
@@ -1086,6 +1093,30 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *ph
     const double sc = 1.0 / (double)pln;
     double *lo = phi + ((size_t)env * nz + k) * pln, *hi = phi + ((size_t)env * nz + (nz - 1 - k)) * pln;
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { lo[idx] = A[idx].x * sc; hi[idx] = A[idx].y * sc; }
+    if (!st) return;
+    double *sb = st + (size_t)env * g.env_stride;
+    double *ulo = sb + g.nc + (size_t)k * pln, *uhi = sb + g.nc + (size_t)(nz - 1 - k) * pln;
+    double *vlo = sb + 2 * (size_t)g.nc + (size_t)k * pln, *vhi = sb + 2 * (size_t)g.nc + (size_t)(nz - 1 - k) * pln;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) {
+        const int j = idx / nx, i = idx - j * nx;
+        const int w_ = j * nx + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nx + i;
+        const double2 c = A[idx], pw = A[w_], ps = A[s_];
+        // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
+        ulo[idx] -= (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] -= (c.y * sc - pw.y * sc) * g.rdx * dts;
+        vlo[idx] -= (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] -= (c.y * sc - ps.y * sc) * g.rdy * dts;
+    }
+}
+
+// vertical half of pressure_correct_velocities!: w -= dts dphi/dz on the interior faces (thread per cell, k >= 1)
+__global__ void k3_correct_w(Geo3 g, double *st, const double *phi, double dts, int B, const uint8_t *mask)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pln = g.nx * g.ny, per = g.nc - pln;
+    if (cell >= per * B) return;
+    const int env = cell / per, c0 = cell - env * per + pln;
+    if (mask && !mask[env]) return;
+    const double *p = phi + (size_t)env * g.nc;
+    st[(size_t)env * g.env_stride + 3 * (size_t)g.nc + c0] -= (p[c0] - p[c0 - pln]) * g.rdz * dts;
 }
 
 // pressure_correct_velocities!

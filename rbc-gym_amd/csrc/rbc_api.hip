@@ -49,7 +49,7 @@ struct rbc_handle {
     int B = 0, nx = 0, nz = 0;
     size_t ncell = 0, env_stride = 0, obs_sz = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    double *d_fields = nullptr, *d_ra = nullptr, *d_tri = nullptr, *d_nu = nullptr, *d_dbg = nullptr, *d_park = nullptr;
+    double *d_fields = nullptr, *d_ra = nullptr, *d_tri = nullptr, *d_nu = nullptr, *d_dbg = nullptr, *d_park = nullptr, *d_celld = nullptr;
     float *d_actions = nullptr, *d_obs = nullptr, *d_state = nullptr;
     uint8_t *d_mask = nullptr;
     uint64_t *d_seeds = nullptr;
@@ -319,7 +319,7 @@ int rbc_destroy(rbc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     destroy3d(h);
-    void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_park, h->d_actions, h->d_obs, h->d_state,
+    void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_park, h->d_celld, h->d_actions, h->d_obs, h->d_state,
                     h->d_mask, h->d_seeds, h->d_flags, h->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -531,6 +531,46 @@ int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const doubl
     }
     for (int c = 0; c < nch; ++c) { h->obs_min[c] = (float)min_vals[c]; h->obs_rng[c] = (float)(max_vals[c] - min_vals[c]); }
     h->obs_norm = nch; h->obs_clip = clip ? 1 : 0; h->obs_maxval = (float)maxval;
+    return RBC_OK;
+}
+
+int rbc_get_cell_distances(rbc_handle *h, double height, double *out)
+{
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = all_initialized(h)) return rc;
+    if (h->s3) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances: 2D envs only (the reference's wrapper reads a 2D mid-line)");
+    if (!h->cfg.write_state) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances needs write_state=1 (it reads the float32 state)");
+    if (!out) return fail(RBC_ERR_INVALID, "null output");
+    if (h->nx > 256) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances: nx <= 256");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->d_celld) HIP_TRY(hipMalloc(&h->d_celld, (size_t)h->B * sizeof(double)));
+    const float *mid = h->d_state + 2 * h->ncell + (size_t)(h->nz / 2 - 1) * h->nx;     // channel UY = w, row int(nz/2) - 1
+    hipLaunchKernelGGL(rbc::cell_distance_kernel, dim3(h->B), dim3(64), 0, h->stream, mid, 5 * h->ncell, h->nx, h->cfg.lx, (float)height, h->d_celld);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->d_celld, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RBC_OK;
+}
+
+void *rbc_dev_cell_dist(rbc_handle *h) { return h ? h->d_celld : nullptr; }
+
+int rbc_debug_cell_distances(int device, const float *uy, int B, int nx, double lx, double height, double *out)
+{
+    if (!uy || !out || B < 1 || nx < 3 || nx > 256) return fail(RBC_ERR_INVALID, "rbc_debug_cell_distances: bad argument (3 <= nx <= 256)");
+    HIP_TRY(hipSetDevice(device));
+    float *d_in = nullptr;
+    double *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)B * nx * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, (size_t)B * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_in, uy, (size_t)B * nx * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rbc::cell_distance_kernel, dim3(B), dim3(64), 0, nullptr, d_in, (size_t)nx, nx, lx, (float)height, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)B * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RBC_ERR_DEVICE, std::string("rbc_debug_cell_distances: ") + hipGetErrorString(e));
     return RBC_OK;
 }
 

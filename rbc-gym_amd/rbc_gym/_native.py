@@ -51,6 +51,9 @@ SYMBOLS = {
     "rbc_synchronize": (C.c_int, [_vp]),
     "rbc_set_rayleigh": (C.c_int, [_vp, _dp]),
     "rbc_set_obs_normalization": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int]),
+    "rbc_get_cell_distances": (C.c_int, [_vp, C.c_double, _dp]),
+    "rbc_dev_cell_dist": (_vp, [_vp]),
+    "rbc_debug_cell_distances": (C.c_int, [C.c_int, _fp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]),
     "rbc_host_alloc": (_vp, [C.c_size_t]),
     "rbc_host_free": (None, [_vp]),
     "rbc_reset": (C.c_int, [_vp, _u8p, _u64p]),
@@ -187,6 +190,19 @@ def copy_ceiling(device=0, nbytes=1 << 30, iters=10):
             "note": "GB/s of bytes read + bytes written, device buffer to device buffer"}
 
 
+def debug_cell_distances(uy, lx=2 * np.pi, height=0.001, device=0):
+    """the device kernel behind NativeSim.get_cell_distances on caller-provided signals uy[B, nx] (parity tests)"""
+    lib = load_library()
+    a = np.ascontiguousarray(uy, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("uy must be (B, nx)")
+    o = np.empty(a.shape[0])
+    rc = lib.rbc_debug_cell_distances(int(device), _ptr(a, _fp), a.shape[0], a.shape[1], float(lx), float(height), _ptr(o, _dp))
+    if rc != RBC_OK:
+        raise RbcError(rc, lib.rbc_last_error().decode())
+    return o
+
+
 def torch_stream_handle(stream):
     """value for rbc_set_stream that makes the sim run ON a torch stream: torch's default stream has handle 0, which the
     C ABI reserves for "the handle's own stream", so it is passed as hipStreamLegacy (1) instead."""
@@ -317,6 +333,12 @@ class NativeSim:
         f = np.empty(self.B, np.int32)
         self._check(self.lib.rbc_get_flags(self.h, _ptr(f, _i32p)))
         return f
+
+    def get_cell_distances(self, height=0.001):
+        """RBCRewardShaping.compute_cell_distances for every env, evaluated on the device (needs write_state=1)"""
+        o = np.empty(self.B)
+        self._check(self.lib.rbc_get_cell_distances(self.h, float(height), _ptr(o, _dp)))
+        return o
 
     def synchronize(self):
         self._check(self.lib.rbc_synchronize(self.h))

@@ -15,6 +15,7 @@ import numpy as np
 from ._gym import gym
 from . import _native
 from .checkpoint import read_checkpoint
+from .sharded import ShardedSim
 from .envs._common import check_checkpoint_grid, checkpoint_index
 from .envs.rbc2D import build_spaces, sim_kwargs
 
@@ -110,8 +111,10 @@ class _BatchedEnv(gym.vector.VectorEnv):
         return self._observations(), rewards, terminated, truncated, info
 
     def step_device(self, actions_device_ptr):
-        """Advance all envs with actions already on the device (float32, batch-major); no host copy,
-        no autoreset, asynchronous on the simulation's stream."""
+        """Advance all envs with actions already on the device (float32, batch-major); no host copy, no autoreset,
+        asynchronous on the simulation's own stream: complete the writes of the actions before the call and
+        `self.sim.synchronize()` (or an event) before another stream reads the device views.  With devices=[...]: a
+        list of pointers, one per shard, each on that shard's GPU."""
         self.sim.step_dev(actions_device_ptr)
 
     def close(self, **kwargs):
@@ -124,7 +127,7 @@ class _BatchedEnv(gym.vector.VectorEnv):
 class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
     def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
                  state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
-                 use_gpu=True, checkpoint=None, render_mode=None, device=0, info_state=True, **_ignored):
+                 use_gpu=True, checkpoint=None, render_mode=None, device=0, devices=None, info_state=True, **_ignored):
         # info_state: True = info["state"] is a fresh array every step (the reference's behaviour), "pinned" = it rotates over
         # three page-locked buffers (3x faster device-to-host copy; an array is overwritten three steps later), False = omitted
         self.num_envs = int(num_envs)
@@ -141,9 +144,13 @@ class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
         self.single_action_space, self.single_observation_space = build_spaces(self.observation_shape, heater_segments,
                                                                                heater_limit, pressure)
         ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
-        self.sim = _native.NativeSim(batch=self.num_envs, device=device,
-                                     **sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments,
-                                                  heater_limit, heater_duration))
+        kw = sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments, heater_limit, heater_duration)
+        # devices=[0, 1, ...]: the envs are split into contiguous ranges, one library handle per GPU (rbc_gym/sharded.py)
+        self.devices = None if devices is None else [int(d) for d in devices]
+        if self.devices is None:
+            self.sim = _native.NativeSim(batch=self.num_envs, device=device, **kw)
+        else:
+            self.sim = ShardedSim(lambda count, dev: _native.NativeSim(batch=count, device=dev, **kw), self.num_envs, self.devices)
         if np.ndim(rayleigh_number) > 0:                 # per-env Rayleigh numbers (Ra sweeps)
             self.sim.set_rayleigh(np.asarray(rayleigh_number, dtype=np.float64))
         self._nch = 5 if pressure else 3
@@ -172,10 +179,17 @@ class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
 
     # -- device-resident rollout API (zero-copy PyTorch-ROCm tensors) --------------------------------
     def device_views(self):
-        p = self.sim.dev_ptrs()
-        B, (oz, ox), (nz, nx) = self.num_envs, self.observation_shape, self.state_shape
-        return {"obs": DeviceArray(p["obs"], (B, 5, oz, ox), "<f4", self), "state": DeviceArray(p["state"], (B, 5, nz, nx), "<f4", self),
-                "nusselt": DeviceArray(p["nusselt"], (B, 2), "<f8", self), "flags": DeviceArray(p["flags"], (B,), "<i4", self)}
+        """zero-copy views of the library's output buffers; with devices=[...] a LIST with one dict per shard, each on its
+        own GPU and covering that shard's contiguous env range (`self.sim.ranges`)"""
+        (oz, ox), (nz, nx) = self.observation_shape, self.state_shape
+
+        def views(p, B):
+            return {"obs": DeviceArray(p["obs"], (B, 5, oz, ox), "<f4", self), "state": DeviceArray(p["state"], (B, 5, nz, nx), "<f4", self),
+                    "nusselt": DeviceArray(p["nusselt"], (B, 2), "<f8", self), "flags": DeviceArray(p["flags"], (B,), "<i4", self)}
+        if self.devices is None:
+            return views(self.sim.dev_ptrs(), self.num_envs)
+        return [dict(views(p, count), device=dev, env_range=(start, start + count))
+                for p, dev, (start, count) in zip(self.sim.dev_ptrs(), self.devices, self.sim.ranges)]
 
     def render(self):
         """One frame per env, as gymnasium's vector envs return them (a tuple): the temperature field through the
@@ -200,7 +214,7 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
     def __init__(self, num_envs=1, rayleigh_number=2500, prandtl_number=0.7, domain=(2, 4 * np.pi, 4 * np.pi),
                  state_shape=(16, 32, 32), temperature_difference=(1, 2), heater_segments=8, heater_limit=0.9,
                  heater_duration=0.125, episode_length=300, dt_solver=0.01, use_gpu=True, checkpoint=None, checkpoint_idx=None,
-                 render_mode=None, device=0, **_ignored):
+                 render_mode=None, device=0, devices=None, **_ignored):
         from .envs.rbc3D import build_spaces3d
         self.num_envs = int(num_envs)
         self.ra, self.pr = rayleigh_number, prandtl_number
@@ -213,9 +227,12 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
         self.single_action_space, self.single_observation_space = build_spaces3d(state_shape, temperature_difference,
                                                                                  heater_segments, heater_limit)
         ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
-        self.sim = _native.NativeSim3D(batch=self.num_envs, device=device, shape=tuple(state_shape), domain=tuple(domain), ra=ra0,
+        def make(count, dev):
+            return _native.NativeSim3D(batch=count, device=dev, shape=tuple(state_shape), domain=tuple(domain), ra=ra0,
                                        pr=float(prandtl_number), t_diff=tuple(temperature_difference), heaters=heater_segments,
                                        heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver)
+        self.devices = None if devices is None else [int(d) for d in devices]
+        self.sim = make(self.num_envs, device) if self.devices is None else ShardedSim(make, self.num_envs, self.devices)
         if np.ndim(rayleigh_number) > 0:
             self.sim.set_rayleigh(np.asarray(rayleigh_number, dtype=np.float64))
         self._finish_init(self.num_envs, episode_length, checkpoint, render_mode)

@@ -61,9 +61,14 @@ class VectorRBCRewardShaping(gym.vector.VectorWrapper):
 
     def step(self, actions):
         obs, reward, term, trunc, info = self.env.step(actions)
-        state = info["state"] if "state" in info else self.env.unwrapped.sim.get_state(3)
-        mid = state[:, 2, int(self.size_state[0] / 2) - 1]                    # UY channel, mid-height row: (B, nx)
-        cd = cell_distances(mid)
+        sim = getattr(self.env.unwrapped, "sim", None)
+        if hasattr(sim, "get_cell_distances"):
+            # the peak search runs on the device, one wave per env, on the float32 state the step kernel just wrote
+            # (bit-identical to cell_distances below; only B doubles cross PCIe instead of the mid-lines or the state)
+            cd = sim.get_cell_distances(0.001)
+        else:
+            state = info["state"] if "state" in info else sim.get_state(3)
+            cd = cell_distances(state[:, 2, int(self.size_state[0] / 2) - 1])      # UY channel, mid-height row: (B, nx)
         w = self.shaping_weight
         info["cell_dist"] = cd
         return obs, (1 - w) * reward + w * ((-cd + np.pi) / np.pi), term, trunc, info

@@ -49,3 +49,48 @@ if __name__ == "__main__":
     ref = np.load(os.path.join(ROOT, "tests", "golden", "flowstats_ref_series.npz"))
     for p in sys.argv[1:]:
         compare(p, ref)
+
+
+def time_map(ens_log_mean, ref_log, nl):
+    """(F, a, rms) of the map  t_ref = a + F n  minimising rms[ ref(n) - ens(a + F n) ] over steps 1..nl (log space)"""
+    t = np.arange(1, len(ens_log_mean) + 1, dtype=float)
+    best = (np.inf, 1.0, 0.0)
+    for F in np.linspace(0.94, 1.04, 201):
+        for a in np.linspace(-0.1, 0.1, 41):
+            err = np.sqrt(np.mean((ref_log[:nl] - np.interp(a + F * t[:nl], t, ens_log_mean)) ** 2))
+            if err < best[0]:
+                best = (err, F, a)
+    return best[1], best[2], best[0]
+
+
+def peak_time(y):
+    """time of the maximum of a series sampled at steps 1, 2, ... (parabola through the three samples around it)"""
+    k = int(np.argmax(y))
+    if k == 0 or k == len(y) - 1:
+        return float(k + 1)
+    a, b, c = y[k - 1], y[k], y[k + 1]
+    return k + 1 + 0.5 * (a - c) / (a - 2 * b + c)
+
+
+def summary(path, ref):
+    """numbers recorded in tests/golden/flowstats3d_series_experiments.json"""
+    g = np.load(path)
+    steps = g["nusselt"].shape[2]
+    rows = []
+    for i, ra in enumerate(ref["ra"]):
+        nu = g["nusselt"][i] - 1
+        m, s = nu.mean(0), nu.std(0, ddof=1)
+        r = ref["nusselt"][i, :steps] - 1
+        nl = min(linear_phase_end(m), steps)
+        f, _ = time_factor(np.log(m), np.log(r), nl)
+        npk = int(np.argmax(m))
+        row = {"ra": float(ra), "z_steps_1_3": [float((r[n] - m[n]) / s[n]) for n in range(3)], "linear_steps": int(nl),
+               "linear_time_factor": float(f)}
+        if 3 < npk < steps - 1:
+            F, a, rms = time_map(np.log(m), np.log(r), npk - 1)
+            tp = np.array([peak_time(x) for x in g["nusselt"][i]])
+            row.update({"prepeak_steps": int(npk - 1), "prepeak_time_map_F": float(F), "prepeak_time_map_a": float(a),
+                        "prepeak_rms_log_resid": float(rms), "peak_time_members_mean": float(tp.mean()),
+                        "peak_time_members_std": float(tp.std(ddof=1)), "peak_time_reference": float(peak_time(ref["nusselt"][i, :steps]))})
+        rows.append(row)
+    return rows

@@ -16,7 +16,7 @@ Outputs: ckpt2d_ra10000.npz   - 3 episodes of train/ckpt_ra10000 (b,u,w f64)
                                 horizontal-mean b profile) computed with numpy from the data.
 Only DATA travels: no reference code is executed or copied.
 """
-import json, os
+import json, os, sys
 import numpy as np
 import h5py
 
@@ -99,6 +99,7 @@ def main():
             be, ue, wc = b[..., e], u[..., e], w[:-1, :, e]
             prof.append(np.stack([be.mean(1), (ue**2).mean(1), (wc**2).mean(1), (be * wc).mean(1), (be**2).mean(1)]))
     np.savez_compressed(f"{OUT}/ckpt2d_ra10000_profiles.npz", profiles=np.array(prof))
+    spectra()
     with open(f"{OUT}/ckpt2d_pins.json", "w") as f:
         json.dump(pins, f, indent=1)
     r = pins["train/ckpt_ra10000"]["episodes"]
@@ -106,8 +107,27 @@ def main():
           "Nu_obs", np.mean([x["nusselt_obs"] for x in r]), "max div", max(x["max_abs_div"] for x in r))
 
 
-if __name__ == "__main__":
-    main()
+sys.path.insert(0, os.path.dirname(OUT))
+from spectral_invariants import SPEC_K, field_spectra  # noqa: E402  (tests/spectral_invariants.py)
+
+
+def spectra():
+    """ckpt2d_ra10000_spectra.npz: mean and standard deviation over the reference's 40 Ra=1e4 episodes (train 20, val 10,
+    test 10; all are x-translates of ONE steady k=2 state) of the translation invariants above: the whole steady field
+    structure, not just five profile moments.  Phases are stored as mean/std of cos and sin."""
+    mods, phs = [], []
+    for split in ("train", "val", "test"):
+        with h5py.File(f"{REF}/{split}/ckpt_ra10000.h5", "r") as f:
+            b = f["b"][...][:, 0]; u = f["u"][...][:, 0]; w = f["w"][...][:, 0]
+        for e in range(b.shape[-1]):
+            m, p = field_spectra(b[..., e], u[..., e], w[:-1, :, e])
+            mods.append(m); phs.append(p)
+    mods, phs = np.array(mods), np.array(phs)
+    np.savez_compressed(f"{OUT}/ckpt2d_ra10000_spectra.npz", k=np.array(SPEC_K), episodes=np.array(len(mods)),
+                        mod_mean=mods.mean(0), mod_std=mods.std(0, ddof=1),
+                        cos_mean=np.cos(phs).mean(0), cos_std=np.cos(phs).std(0, ddof=1),
+                        sin_mean=np.sin(phs).mean(0), sin_std=np.sin(phs).std(0, ddof=1))
+    print("spectra: |B_2| rows 0..2", mods.mean(0)[0, 1, :3], "rel spread", (mods.std(0, ddof=1)[0, 1, :3] / mods.mean(0)[0, 1, :3]))
 
 
 def small_h5():
@@ -122,4 +142,5 @@ def small_h5():
 
 
 if __name__ == "__main__":
+    main()
     small_h5()

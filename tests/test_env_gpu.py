@@ -75,10 +75,25 @@ def test_checkpoint_kwarg(gym, golden_dir, ckpt_ra1e4):
 
 
 def test_render_rgb_array(gym):
-    env = gym.make(ID, render_mode="rgb_array", heater_duration=0.3)
+    """render() (rbc2D.py:214-261): the temperature channel of the state through matplotlib's turbo map on
+    [1, 2 + heater_limit], z flipped so that the hot plate is the LAST image row (pygame's origin is top left), returned
+    as (nz, nx, 3) uint8.  Restated here directly: frame[r, x] = turbo((T[nz-1-r, x] - 1) / (1 + heater_limit))."""
+    import matplotlib
+    for limit in (0.75, 0.3):
+        env = gym.make(ID, render_mode="rgb_array", heater_duration=0.3, heater_limit=limit)
+        env.reset(seed=0)
+        for _ in range(3):
+            _, _, _, _, info = env.step(env.action_space.sample())
+        img = env.render()
+        assert img.shape == (64, 96, 3) and img.dtype == np.uint8
+        T = info["state"][0]                                                     # (nz, nx) float32, row 0 = bottom
+        want = matplotlib.colormaps["turbo"]((T[::-1, :] - 1) / ((2 + limit) - 1), bytes=True)[:, :, :3]
+        assert np.array_equal(img, want)
+        assert img[-1, :, 0].mean() > img[-1, :, 2].mean() and img[0, :, 2].mean() > img[0, :, 0].mean()   # hot (red) below, cold (blue) on top
+        env.close()
+    env = gym.make(ID, heater_duration=0.3)
     env.reset(seed=0)
-    img = env.render()
-    assert img.shape == (64, 96, 3) and img.dtype == np.uint8
+    assert env.render() is None                                                   # no render mode: a warning and None (rbc2D.py:215-220)
     env.close()
 
 
@@ -110,6 +125,53 @@ def test_vector_env_matches_single_envs_and_autoresets(gym):
     venv.close()
     for e in singles:
         e.close()
+
+
+def test_multi_device_vector_env_equals_the_single_handle_env(gym):
+    """devices=[...]: one library handle per GPU, contiguous env ranges, driven from one thread per handle
+    (rbc_gym/sharded.py).  On a one-GPU box devices=[0, 0] puts both shards on the same card: observations, rewards,
+    infos, autoreset and the s+i seeding across the shard boundary must be bitwise those of the single-handle env
+    (env instances are independent and the kernel is deterministic)."""
+    torch = pytest.importorskip("torch")
+    n = 5                                                 # uneven split: shards of 3 and 2 envs
+    kw = dict(heater_duration=0.25, episode_length=0.5, pressure=True)
+    one = gym.make_vec(ID, num_envs=n, **kw)
+    two = gym.make_vec(ID, num_envs=n, devices=[0, 0], **kw)
+    assert two.unwrapped.sim.ranges == [(0, 3), (3, 2)]
+    o1, i1 = one.reset(seed=77)
+    o2, i2 = two.reset(seed=77)
+    assert np.array_equal(o1, o2) and np.array_equal(i1["state"], i2["state"])
+    rng = np.random.default_rng(3)
+    for n_step in range(4):                               # step 3 is the NEXT_STEP autoreset of every env
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        r1, r2 = one.step(a), two.step(a)
+        for x, y in zip(r1[:4], r2[:4]):
+            assert np.array_equal(x, y)
+        for k in r1[4]:
+            assert np.array_equal(r1[4][k], r2[4][k]), k
+    views = two.unwrapped.device_views()
+    assert isinstance(views, list) and [v["env_range"] for v in views] == [(0, 3), (3, 5)]
+    two.unwrapped.sim.synchronize()
+    dev_obs = np.concatenate([torch.as_tensor(v["obs"], device=f"cuda:{v['device']}").cpu().numpy() for v in views])
+    assert np.array_equal(dev_obs, r2[0])
+    # partial autoreset that straddles the shard boundary: per-env episode lengths via different start times
+    m = np.array([0, 0, 1, 1, 0], np.uint8)
+    two.unwrapped.sim.reset(np.arange(n, dtype=np.uint64) + 500, mask=m)
+    one.unwrapped.sim.reset(np.arange(n, dtype=np.uint64) + 500, mask=m)
+    f1, f2 = one.unwrapped.sim.get_fields(), two.unwrapped.sim.get_fields()
+    for x, y in zip(f1, f2):
+        assert np.array_equal(x, y)
+    one.close(); two.close()
+    # 3D, per-env Rayleigh numbers across the boundary
+    ras = [2500.0, 5000.0, 7000.0]
+    v1 = gym.make_vec(ID3, num_envs=3, state_shape=(8, 16, 16), rayleigh_number=ras)
+    v2 = gym.make_vec(ID3, num_envs=3, state_shape=(8, 16, 16), rayleigh_number=ras, devices=[0, 0])
+    a1, _ = v1.reset(seed=5); a2, _ = v2.reset(seed=5)
+    assert np.array_equal(a1, a2)
+    act = rng.uniform(-1, 1, (3, 8, 8)).astype(np.float32)
+    s1, s2 = v1.step(act), v2.step(act)
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1]) and np.array_equal(s1[4]["nusselt"], s2[4]["nusselt"])
+    v1.close(); v2.close()
 
 
 def test_device_views_are_zero_copy_torch_tensors(gym):
@@ -334,6 +396,16 @@ def test_from_rest_ensemble_lands_on_the_reference_attractor(golden_dir):
     assert np.allclose(prof[-3:][::-1], 3.0 - np.array([1.96119, 1.88460, 1.81012]), atol=1e-5)
     assert abs(b.mean() - 1.5) < 1e-6
     sim.close()
+    # the WHOLE steady field, not five moments: per-row moduli of the x-spectra of b, u, w at k = 0, 2, 4, 6, 8 and the
+    # b-w / u-w cross phases are invariant under the x-translations that separate the reference's 40 episodes
+    # (tests/golden/ckpt2d_ra10000_spectra.npz: their relative spread is 1e-5).  ~900 z-scores of moduli: the bar is 5; the
+    # build with the other advecting-velocity rule (-DRBC_SYMLEVEL=1) misses it by far (scripts/spectral_pin.py).
+    from spectral_invariants import spectral_z_scores
+    spec_ref = np.load(os.path.join(golden_dir, "ckpt2d_ra10000_spectra.npz"))
+    zm, dphase, _, _ = spectral_z_scores(b[on], u[on], w[on], spec_ref)
+    assert zm.size > 500 and dphase.size > 300
+    assert np.abs(zm).max() < 5.0 and np.sqrt(np.mean(zm ** 2)) < 1.6, (np.abs(zm).max(), np.sqrt(np.mean(zm ** 2)))   # recorded: 1.9 / 1.1; SYMLEVEL=1: 103 / 12
+    assert dphase.max() < 1e-3, dphase.max()                                # phases are symmetry-locked constants
 
 
 def test_ra_sweep_ensembles_match_the_reference_episode_statistics():
@@ -409,3 +481,46 @@ def test_pinned_info_state_matches_fresh_arrays(gym):
         seen.append(ib["state"])
     assert seen[0] is not seen[1] and seen[3].__array_interface__["data"][0] == seen[0].__array_interface__["data"][0]   # 3 buffers rotate
     a.close(); b.close()
+
+
+def test_device_side_cell_distances_are_bit_identical_to_the_numpy_wrapper(gym):
+    """RBCRewardShaping's peak search on the device (one wave per env; rbc_get_cell_distances) against the host code
+    (wrappers/shaping.py, itself checked against scipy.signal.find_peaks in tests/test_wrappers.py): random signals with flat
+    tops, end peaks, all-positive stretches, heights around the 0.001 threshold -- bit for bit; then through the vector
+    wrapper on a convecting batch."""
+    from rbc_gym import _native, wrappers as W
+    rng = np.random.default_rng(11)
+    x = np.linspace(0, 2 * np.pi, 96, endpoint=False)
+    rows = [np.sin(x), np.sin(2 * x), np.sin(3 * x) + 0.3, np.zeros(96), np.full(96, 0.5), np.abs(np.sin(2 * x)) + 0.1,
+            0.001 * np.sin(4 * x), 0.0011 * np.sin(4 * x), np.sin(2 * x) + 1.5, np.where(np.sin(5 * x) > 0.5, 0.7, -0.2)]
+    for _ in range(300):
+        k = rng.integers(1, 12)
+        s = sum(rng.normal() * np.sin(m * x + rng.uniform(0, 6.3)) for m in range(1, k + 1)) * rng.choice([1e-3, 0.05, 1.0])
+        if rng.random() < 0.3:
+            s = np.round(s * 4) / 4                          # plateaus
+        if rng.random() < 0.3:
+            s = s + rng.uniform(0, 2)                        # mostly positive: exercises the same-cell rule
+        rows.append(s)
+    batch = np.array(rows, dtype=np.float32)
+    dev = _native.debug_cell_distances(batch)
+    host = W.cell_distances(batch)
+    assert np.array_equal(dev, host), np.nonzero(dev != host)
+    assert len(np.unique(host)) > 20                        # the cases are not degenerate
+    for nx in (3, 7, 64, 128, 256):
+        b2 = rng.normal(size=(50, nx)).astype(np.float32)
+        assert np.array_equal(_native.debug_cell_distances(b2, lx=3.0), W.cell_distances(b2, lx=3.0))
+    n = 16
+    venv = W.VectorRBCRewardShaping(gym.make_vec(ID, num_envs=n, rayleigh_number=list(np.geomspace(1e4, 1e6, n))), shaping_weight=0.25)
+    raw = gym.make_vec(ID, num_envs=n, rayleigh_number=list(np.geomspace(1e4, 1e6, n)))
+    venv.reset(seed=2); raw.reset(seed=2)
+    seen = set()
+    for _ in range(30):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        _, r, _, _, info = venv.step(a)
+        _, r0, _, _, i0 = raw.step(a)
+        cd = W.cell_distances(i0["state"][:, 2, 31])
+        assert np.array_equal(info["cell_dist"], cd)
+        assert np.array_equal(r, 0.75 * r0 + 0.25 * ((-cd + np.pi) / np.pi))
+        seen.update(cd.tolist())
+    assert len(seen) > 3                                    # convection has set in: several distinct cell distances occurred
+    venv.close(); raw.close()

@@ -1,6 +1,8 @@
 """GPU parity, 3D: the streaming HIP path (through the C ABI) against the 3D CPU oracle on
 identical inputs (fp64; tolerances per test).  The oracle itself is anchored on the 2D one
 (tests/test_oracle3d.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -243,6 +245,58 @@ def test_flowstats_pin_p4(native):
         assert abs(means[j] - ref[ra]) < tol * ref[ra], (ra, means[j], ref[ra])
     # the power law of the notebook's fit, Nu_max ~ 0.2211 Ra^0.2742 (flowstats_plots.ipynb cell 4), bounds the series
     assert np.all(nus[200:].max(0).reshape(seeds, len(ras)) < 1.25 * 0.2211 * np.array(ras) ** 0.2742 + 1.0)
+
+
+def test_flowstats_series_pin(native, golden_dir):
+    """Time-resolved pin on the reference's own data: Nu(t) of the 14 zero-action runs behind experiments/flowstats
+    (tests/golden/flowstats_ref_series.npz, extracted from flowstats_ra.pkl by a non-executing opcode walk,
+    tests/golden/extract_flowstats.py) against an 8-member ensemble per Rayleigh number on the native 3D stepper at the
+    reference's protocol (32x64x64, heater_duration 0.25, dt_solver 0.005; flowstats_ra.py:27-36).  The reference is ONE
+    realisation per Ra drawn from Julia's RNG, so every check is statistical: z = (ref - ensemble mean) / member std.
+
+      (a) steps 1-3, all 14 Ra: the decay of the random kick and the first growth, |z| < 4.5 (recorded 16-member run:
+          max 2.6 of 42).  Nu-1 scales with kick^2: this pins the IC amplitude and the first control interval.
+      (b) overshoot: the step of the first Nusselt maximum equals the ensemble's within one step (Ra >= 750).
+      (c) clock: the time map t_ref = a + F n that carries the ensemble mean onto the reference's pre-peak curve has
+          F = 0.982 +- 0.001 (mean over Ra >= 4000 of the recorded run): the reference's series runs 1.8 % slower than
+          the documented protocol integrated exactly -- 49 instead of 50 solver steps per env.step reproduce it
+          (F = 1.001 +- 0.001, tests/golden/flowstats3d_series_experiments.json), halving dt_solver or replacing RK3 by three
+          Euler stages does not move it.  The reference's sources integrate to stop_time (rbc_sim3D_api.jl:63,88-89), which is
+          what this build does; the assertion below brackets the KNOWN factor so that a clock change of one solver step in
+          either direction (F = 1.00 or 0.96) fails.  DESIGN.md section 4 has the full account.
+      (d) the peak Nusselt number within 6 %.
+    """
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "scripts"))
+    from flowstats3d_series import run_series
+    from flowstats3d_compare import time_map
+    ref = np.load(os.path.join(golden_dir, "flowstats_ref_series.npz"))
+    ras, seeds, steps = ref["ra"], 8, 45
+    out = run_series(ras, seeds, steps, seed0=4242)
+    nu = out["nusselt"]                                              # [ra, member, step]
+    infl = np.sqrt(1.0 + 1.0 / seeds)
+    worst, Fs = 0.0, []
+    for i, ra in enumerate(ras):
+        m, s = (nu[i] - 1).mean(0), (nu[i] - 1).std(0, ddof=1)
+        r = ref["nusselt"][i, :steps] - 1
+        z = (r[:3] - m[:3]) / (s[:3] * infl)
+        worst = max(worst, float(np.abs(z).max()))
+        assert np.all(np.abs(z) < 4.5), (ra, z)                       # (a)
+        if ra < 750:
+            continue                                                  # Ra=500 peaks at step ~65, outside this window
+        am = nu[i].argmax(1)
+        ar = int(np.argmax(ref["nusselt"][i, :steps]))
+        assert am.max() < steps - 1, (ra, am)
+        assert abs(ar - np.median(am)) <= 1, (ra, ar, am)             # (b)
+        pk = nu[i].max(1)
+        assert abs(ref["nusselt"][i, :steps].max() - pk.mean()) < 0.06 * pk.mean(), (ra, pk.mean())       # (d)
+        if ra >= 4000:
+            npk = int(np.argmax(m))
+            F, a, rms = time_map(np.log(m), np.log(r), npk - 1)
+            assert rms < 0.03 and 0.955 < F < 1.005 and abs(a) < 0.11, (ra, F, a, rms)
+            Fs.append(F)
+    assert 0.972 < np.mean(Fs) < 0.992, Fs                            # (c): recorded 0.9822 +- 0.0012
+    print(f"flowstats series pin: max |z| over steps 1-3 = {worst:.2f}, mean pre-peak time factor F = {np.mean(Fs):.4f}")
 
 
 @pytest.mark.parametrize("shape", [SHAPE, (16, 32, 32)], ids=["tiles-8x8", "tiles-16x4"])

@@ -75,3 +75,74 @@ def test_two_ranks_reproduce_one_process():
     assert sorted(merged) == [0, 1, 2, 3]
     for i in range(4):
         assert merged[i] == serial[i]                       # bitwise: no cross-env coupling anywhere
+
+
+class _FakeSim:
+    """stand-in for NativeSim in the host-logic test of rbc_gym.sharded.ShardedSim: env e of the global batch holds the
+    value `100 * device + local index`, a step adds the env's action sum; records the thread it was driven from"""
+
+    def __init__(self, count, dev):
+        import threading
+        self.B, self.dev, self.heaters, self.lib = count, dev, 12, None
+        self.x = 100.0 * dev + np.arange(count, dtype=np.float64)
+        self.seeds = None
+        self.threads = set()
+        self._t = threading
+
+    def reset(self, seeds, mask=None):
+        self.threads.add(self._t.get_ident())
+        m = np.ones(self.B, bool) if mask is None else np.asarray(mask, bool)
+        assert seeds.shape == (self.B,) and m.shape == (self.B,)
+        self.seeds = np.where(m, seeds, 0 if self.seeds is None else self.seeds)
+        self.x = np.where(m, 100.0 * self.dev + np.arange(self.B), self.x)
+
+    def step(self, a):
+        self.threads.add(self._t.get_ident())
+        assert a.shape == (self.B, 12) and a.dtype == np.float32
+        self.x = self.x + a.sum(1)
+        return True
+
+    def get_obs(self, nch=3):
+        return np.repeat(self.x[:, None], nch, 1)
+
+    def get_nusselt(self):
+        return self.x.copy(), -self.x
+
+    def get_flags(self):
+        return np.zeros(self.B, np.int32)
+
+    def close(self):
+        pass
+
+
+def test_sharded_sim_concatenates_in_global_env_order():
+    """rbc_gym.sharded.ShardedSim (the multi-GPU VectorEnv's engine) with three fake device handles: contiguous env
+    ranges, per-shard slices of seeds / masks / actions, results back in global order, one driver thread per handle."""
+    from rbc_gym.sharded import ShardedSim
+    made = []
+
+    def make(count, dev):
+        made.append(_FakeSim(count, dev))
+        return made[-1]
+    sh = ShardedSim(make, 10, [0, 1, 2])
+    assert sh.ranges == [(0, 4), (4, 3), (7, 3)] and [m.B for m in made] == [4, 3, 3]
+    sh.reset(np.arange(10, dtype=np.uint64) + 50)
+    assert [list(m.seeds) for m in made] == [[50, 51, 52, 53], [54, 55, 56], [57, 58, 59]]
+    a = np.zeros((10, 12), np.float32)
+    a[:, 0] = np.arange(10) / 10
+    assert sh.step(a)
+    nus, nuo = sh.get_nusselt()
+    want = np.concatenate([100.0 * d + np.arange(c) for d, c in ((0, 4), (1, 3), (2, 3))]) + np.arange(10, dtype=np.float32) / 10
+    assert np.allclose(nus, want) and np.allclose(nuo, -want) and sh.get_obs(5).shape == (10, 5)
+    mask = np.zeros(10, np.uint8)
+    mask[[3, 4]] = 1                                      # straddles the first shard boundary; shard 2 is not touched at all
+    before = made[2].x.copy()
+    sh.reset(np.arange(10, dtype=np.uint64) + 900, mask=mask)
+    assert made[0].seeds[3] == 903 and made[1].seeds[0] == 904 and made[0].seeds[0] == 50 and np.array_equal(made[2].x, before)
+    assert made[0].x[3] == 3.0 and made[1].x[0] == 100.0 and abs(made[0].x[1] - 1.1) < 1e-6      # env 1 kept its stepped value
+    assert len(set().union(*[m.threads for m in made])) >= 1
+    with pytest.raises(ValueError):
+        sh.step(np.zeros((9, 12), np.float32))
+    with pytest.raises(ValueError):
+        ShardedSim(make, 2, [0, 1, 2])
+    sh.close()
