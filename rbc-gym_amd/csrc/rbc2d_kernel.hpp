@@ -27,7 +27,6 @@ namespace rbc {
 
 constexpr int CZ = 8;              // cells per thread along z
 constexpr int MAX_HEATERS = 32;
-constexpr int SCRATCH_DOUBLES = 1090;  // twiddles (192) + reduction scratch (NT+130); sits in FRONT of the fields
 
 enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENCY = 3 };
 
@@ -138,16 +137,16 @@ __device__ inline double normal_deviate(uint64_t seed, uint32_t field, uint32_t 
 // reconstruction stencils (uniform grid).  a..f are six consecutive values psi[-3..+2]
 // around the target: centre->face: target face sits between c and d; face->centre alike.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double left5(double a, double b, double c, double d, double e)
-{ return (2.0 / 60.0) * a - (13.0 / 60.0) * b + (47.0 / 60.0) * c + (27.0 / 60.0) * d - (3.0 / 60.0) * e; }
-__device__ __forceinline__ double right5(double b, double c, double d, double e, double f)
-{ return (27.0 / 60.0) * c - (3.0 / 60.0) * b + (47.0 / 60.0) * d - (13.0 / 60.0) * e + (2.0 / 60.0) * f; }
-__device__ __forceinline__ double left3(double b, double c, double d)
-{ return (5.0 / 6.0) * c - (1.0 / 6.0) * b + (2.0 / 6.0) * d; }
-__device__ __forceinline__ double right3(double c, double d, double e)
-{ return (2.0 / 6.0) * c + (5.0 / 6.0) * d - (1.0 / 6.0) * e; }
-__device__ __forceinline__ double sym4(double b, double c, double d, double e)
-{ return (7.0 / 12.0) * (c + d) - (1.0 / 12.0) * (b + e); }
+template <typename T> __device__ __forceinline__ T left5(T a, T b, T c, T d, T e)
+{ return T(2.0 / 60.0) * a - T(13.0 / 60.0) * b + T(47.0 / 60.0) * c + T(27.0 / 60.0) * d - T(3.0 / 60.0) * e; }
+template <typename T> __device__ __forceinline__ T right5(T b, T c, T d, T e, T f)
+{ return T(27.0 / 60.0) * c - T(3.0 / 60.0) * b + T(47.0 / 60.0) * d - T(13.0 / 60.0) * e + T(2.0 / 60.0) * f; }
+template <typename T> __device__ __forceinline__ T left3(T b, T c, T d)
+{ return T(5.0 / 6.0) * c - T(1.0 / 6.0) * b + T(2.0 / 6.0) * d; }
+template <typename T> __device__ __forceinline__ T right3(T c, T d, T e)
+{ return T(2.0 / 6.0) * c + T(5.0 / 6.0) * d - T(1.0 / 6.0) * e; }
+template <typename T> __device__ __forceinline__ T sym4(T b, T c, T d, T e)
+{ return T(7.0 / 12.0) * (c + d) - T(1.0 / 12.0) * (b + e); }
 
 // upwinded value: vel>0 takes the left-biased reconstruction (== upwind_biased_product/vel).
 // Both reconstructions are materialised (empty asm) so hipcc emits one v_cndmask pair instead of
@@ -155,53 +154,52 @@ __device__ __forceinline__ double sym4(double b, double c, double d, double e)
 #ifndef RBC_BRANCHFREE
 #define RBC_BRANCHFREE 1
 #endif
-__device__ __forceinline__ double pick(double vel, double L, double R)
+template <typename T> __device__ __forceinline__ T pick(T vel, T L, T R)
 {
 #if RBC_BRANCHFREE
     asm volatile("" : "+v"(L), "+v"(R));
 #endif
-    return vel * (vel > 0.0 ? L : R);
+    return vel * (vel > T(0) ? L : R);
 }
-__device__ __forceinline__ double upw5(double vel, double a, double b, double c, double d, double e, double f)
+template <typename T> __device__ __forceinline__ T upw5(T vel, T a, T b, T c, T d, T e, T f)
 { return pick(vel, left5(a, b, c, d, e), right5(b, c, d, e, f)); }
 
 // wall-aware version: ok5/ok3 select 5th / 3rd / 1st order (both biases share one test)
-__device__ __forceinline__ double upwz(double vel, double a, double b, double c, double d, double e, double f,
-                                        bool ok5, bool ok3)
+template <typename T> __device__ __forceinline__ T upwz(T vel, T a, T b, T c, T d, T e, T f, bool ok5, bool ok3)
 {
-    double L = ok5 ? left5(a, b, c, d, e) : (ok3 ? left3(b, c, d) : c);
-    double R = ok5 ? right5(b, c, d, e, f) : (ok3 ? right3(c, d, e) : d);
+    T L = ok5 ? left5(a, b, c, d, e) : (ok3 ? left3(b, c, d) : c);
+    T R = ok5 ? right5(b, c, d, e, f) : (ok3 ? right3(c, d, e) : d);
     return pick(vel, L, R);
 }
-__device__ __forceinline__ double symz(double b, double c, double d, double e, bool ok4)
-{ return ok4 ? sym4(b, c, d, e) : 0.5 * (c + d); }
+template <typename T> __device__ __forceinline__ T symz(T b, T c, T d, T e, bool ok4)
+{ return ok4 ? sym4(b, c, d, e) : T(0.5) * (c + d); }
 
 // ------------------------------------------------------------------------------------------
 // small complex DFTs in registers (forward, e^{-i...}); inverse = call with re/im swapped
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dft8(double *re, double *im)
+template <typename T> __device__ __forceinline__ void dft8(T *re, T *im)
 {
-    const double h = 0.70710678118654752440;
+    const T h = T(0.70710678118654752440);
     // stage 1: pairs (j, j+4)
-    double ar[8], ai[8];
+    T ar[8], ai[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         ar[j] = re[j] + re[j + 4]; ai[j] = im[j] + im[j + 4];
         ar[j + 4] = re[j] - re[j + 4]; ai[j + 4] = im[j] - im[j + 4];
     }
     // twiddle the odd half by W8^j
-    { double t;
+    { T t;
       t = ar[5]; ar[5] = h * (ar[5] + ai[5]); ai[5] = h * (ai[5] - t);           // *(1-i)/sqrt2
       t = ar[6]; ar[6] = ai[6]; ai[6] = -t;                                      // *(-i)
       t = ar[7]; ar[7] = h * (ai[7] - ar[7]); ai[7] = -h * (t + ai[7]); }        // *(-1-i)/sqrt2
     // two DFT-4 on (0,1,2,3) -> even outputs, (4,5,6,7) -> odd outputs
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        double *xr = ar + 4 * g, *xi = ai + 4 * g;
-        double s0r = xr[0] + xr[2], s0i = xi[0] + xi[2];
-        double d0r = xr[0] - xr[2], d0i = xi[0] - xi[2];
-        double s1r = xr[1] + xr[3], s1i = xi[1] + xi[3];
-        double d1r = xr[1] - xr[3], d1i = xi[1] - xi[3];
+        T *xr = ar + 4 * g, *xi = ai + 4 * g;
+        T s0r = xr[0] + xr[2], s0i = xi[0] + xi[2];
+        T d0r = xr[0] - xr[2], d0i = xi[0] - xi[2];
+        T s1r = xr[1] + xr[3], s1i = xi[1] + xi[3];
+        T d1r = xr[1] - xr[3], d1i = xi[1] - xi[3];
         // outputs k=0..3 of the DFT-4: s0+s1, d0 - i d1, s0-s1, d0 + i d1
         re[g + 0] = s0r + s1r; im[g + 0] = s0i + s1i;
         re[g + 2] = d0r + d1i; im[g + 2] = d0i - d1r;
@@ -210,26 +208,26 @@ __device__ __forceinline__ void dft8(double *re, double *im)
     }
 }
 
-__device__ __forceinline__ void dft3(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2)
+template <typename T> __device__ __forceinline__ void dft3(T &r0, T &i0, T &r1, T &i1, T &r2, T &i2)
 {
-    const double s = 0.86602540378443864676;
-    double tr = r1 + r2, ti = i1 + i2;
-    double mr = r0 - 0.5 * tr, mi = i0 - 0.5 * ti;
-    double dr = s * (r1 - r2), di = s * (i1 - i2);
+    const T s = T(0.86602540378443864676);
+    T tr = r1 + r2, ti = i1 + i2;
+    T mr = r0 - T(0.5) * tr, mi = i0 - T(0.5) * ti;
+    T dr = s * (r1 - r2), di = s * (i1 - i2);
     r0 += tr; i0 += ti;
     r1 = mr + di; i1 = mi - dr;
     r2 = mr - di; i2 = mi + dr;
 }
 
 // DFT-12 by the prime-factor (Good-Thomas) map: n=(4n1+3n2)%12, k=(4k1+9k2)%12; no twiddles
-__device__ __forceinline__ void dft12(double *re, double *im)
+template <typename T> __device__ __forceinline__ void dft12(T *re, T *im)
 {
-    double tr[3][4], ti[3][4];
+    T tr[3][4], ti[3][4];
 #pragma unroll
     for (int n2 = 0; n2 < 4; ++n2) {
-        double r0 = re[(3 * n2) % 12], i0 = im[(3 * n2) % 12];
-        double r1 = re[(4 + 3 * n2) % 12], i1 = im[(4 + 3 * n2) % 12];
-        double r2 = re[(8 + 3 * n2) % 12], i2 = im[(8 + 3 * n2) % 12];
+        T r0 = re[(3 * n2) % 12], i0 = im[(3 * n2) % 12];
+        T r1 = re[(4 + 3 * n2) % 12], i1 = im[(4 + 3 * n2) % 12];
+        T r2 = re[(8 + 3 * n2) % 12], i2 = im[(8 + 3 * n2) % 12];
         dft3(r0, i0, r1, i1, r2, i2);
         tr[0][n2] = r0; ti[0][n2] = i0;
         tr[1][n2] = r1; ti[1][n2] = i1;
@@ -237,15 +235,67 @@ __device__ __forceinline__ void dft12(double *re, double *im)
     }
 #pragma unroll
     for (int k1 = 0; k1 < 3; ++k1) {
-        double s0r = tr[k1][0] + tr[k1][2], s0i = ti[k1][0] + ti[k1][2];
-        double d0r = tr[k1][0] - tr[k1][2], d0i = ti[k1][0] - ti[k1][2];
-        double s1r = tr[k1][1] + tr[k1][3], s1i = ti[k1][1] + ti[k1][3];
-        double d1r = tr[k1][1] - tr[k1][3], d1i = ti[k1][1] - ti[k1][3];
+        T s0r = tr[k1][0] + tr[k1][2], s0i = ti[k1][0] + ti[k1][2];
+        T d0r = tr[k1][0] - tr[k1][2], d0i = ti[k1][0] - ti[k1][2];
+        T s1r = tr[k1][1] + tr[k1][3], s1i = ti[k1][1] + ti[k1][3];
+        T d1r = tr[k1][1] - tr[k1][3], d1i = ti[k1][1] - ti[k1][3];
         re[(4 * k1) % 12] = s0r + s1r;          im[(4 * k1) % 12] = s0i + s1i;
         re[(4 * k1 + 9) % 12] = d0r + d1i;      im[(4 * k1 + 9) % 12] = d0i - d1r;
         re[(4 * k1 + 18) % 12] = s0r - s1r;     im[(4 * k1 + 18) % 12] = s0i - s1i;
         re[(4 * k1 + 27) % 12] = d0r - d1i;     im[(4 * k1 + 27) % 12] = d0i + d1r;
     }
+}
+
+// DFT-16 as two DFT-8 (even / odd samples) + one radix-2 butterfly with W16^k
+template <typename T> __device__ __forceinline__ void dft16(T *re, T *im)
+{
+    T er[8], ei[8], orr[8], oi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { er[j] = re[2 * j]; ei[j] = im[2 * j]; orr[j] = re[2 * j + 1]; oi[j] = im[2 * j + 1]; }
+    dft8(er, ei);
+    dft8(orr, oi);
+    const T c1 = T(0.92387953251128675613), s1 = T(0.38268343236508977173), h = T(0.70710678118654752440);
+    // W16^k = wr[k] + i wi[k], k = 0..7
+    const T wr[8] = {T(1), c1, h, s1, T(0), -s1, -h, -c1};
+    const T wi[8] = {T(0), -s1, -h, -c1, T(-1), -c1, -h, -s1};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const T tr = orr[k] * wr[k] - oi[k] * wi[k], ti = orr[k] * wi[k] + oi[k] * wr[k];
+        re[k] = er[k] + tr; im[k] = ei[k] + ti;
+        re[k + 8] = er[k] - tr; im[k + 8] = ei[k] - ti;
+    }
+}
+
+// DFT-24 by the prime-factor map n = (8 n1 + 3 n2) % 24, k = (16 k1 + 9 k2) % 24 (n1, k1 < 3; n2, k2 < 8): no twiddles
+template <typename T> __device__ __forceinline__ void dft24(T *re, T *im)
+{
+    T tr[3][8], ti[3][8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) {
+        T r0 = re[(3 * n2) % 24], i0 = im[(3 * n2) % 24];
+        T r1 = re[(8 + 3 * n2) % 24], i1 = im[(8 + 3 * n2) % 24];
+        T r2 = re[(16 + 3 * n2) % 24], i2 = im[(16 + 3 * n2) % 24];
+        dft3(r0, i0, r1, i1, r2, i2);
+        tr[0][n2] = r0; ti[0][n2] = i0;
+        tr[1][n2] = r1; ti[1][n2] = i1;
+        tr[2][n2] = r2; ti[2][n2] = i2;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        dft8(tr[k1], ti[k1]);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) { re[(16 * k1 + 9 * k2) % 24] = tr[k1][k2]; im[(16 * k1 + 9 * k2) % 24] = ti[k1][k2]; }
+    }
+}
+
+// the second factor of the x transform: NX = 8 * N2
+template <int N2, typename T> __device__ __forceinline__ void dft_n2(T *re, T *im)
+{
+    static_assert(N2 == 8 || N2 == 12 || N2 == 16 || N2 == 24, "x transform sizes: NX = 8 * {8, 12, 16, 24}");
+    if (N2 == 8) dft8(re, im);
+    else if (N2 == 12) dft12(re, im);
+    else if (N2 == 16) dft16(re, im);
+    else dft24(re, im);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,26 +304,45 @@ __device__ __forceinline__ void dft12(double *re, double *im)
 // address VGPR per stencil column then reaches every field and row through the 16-bit
 // immediate offset of ds_read_b64.
 // ------------------------------------------------------------------------------------------
-template <int NX, int NZ>
+template <int NX, int NZ, typename T = double>
 struct Geo {
-    static_assert(NX == 96, "x transform is an 8x12 FFT: NX must be 96");
+    static_assert(NX % 64 == 0 || NX == 96, "lanes run along x: NX in {64, 96, 128, 192}");
     static_assert(NZ % (2 * CZ) == 0, "NZ must be a multiple of 16");
+    static constexpr int N2 = NX / 8;                     // x transform = 8 x N2 Cooley-Tukey (N2 in {8, 12, 16, 24})
     static constexpr int NC = NZ / CZ;
-    static constexpr int NT = NX * NC;
+    static constexpr int NT = NX * NC;                    // threads: one per column and z chunk
+    static_assert(NT <= 1024, "one workgroup per env: NX * NZ <= 8192");
     static constexpr int NCELL = NX * NZ;
     static constexpr int NH = NX / 2 + 1;                 // stored Fourier columns
-    static constexpr int RS = 3 * NX;                     // LDS row stride (doubles)
+    static constexpr int NXP = (NX + 63) / 64 * 64;       // NX rounded up to whole waves (z sweeps: lanes [0,NX) up, [NXP,NXP+NX) down)
+    static_assert(NT >= 2 * NXP, "the two z sweeps need 2 * NXP threads");
+    static constexpr int RS = 3 * NX;                     // LDS row stride (reals)
     static constexpr int FU = 0, FW = NX, FB = 2 * NX;    // field offsets inside a row
     static constexpr int GUARD = 3;                       // stencil rows that may be touched beyond a wall
-    // [scratch | NZ field rows | GUARD rows]: the scratch doubles as the guard below row 0, so every
-    // stencil row offset is a compile-time immediate (values read from guards are selected away)
-    static_assert(SCRATCH_DOUBLES >= GUARD * RS, "front scratch must cover the lower guard rows");
-    // the z solve parks pivot rows 16.. and one junction row (NX doubles) over the top guard rows; the little that
-    // does not fit extends the allocation
-    static constexpr int ZTAIL = ((NZ / 2 + 1 - 16) * NH + NX > GUARD * RS) ? (NZ / 2 + 1 - 16) * NH + NX - GUARD * RS : 0;
-    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH_DOUBLES + 3 * NCELL + GUARD * RS + ZTAIL) * sizeof(double);
+    // [scratch | NZ field rows | GUARD rows]: the scratch (twiddles 2*NX, then reductions / column-scan partials / pivot rows:
+    // NT + 130) doubles as the guard below row 0, so every stencil row offset is a compile-time immediate (values read from
+    // guards are selected away)
+    static constexpr int TW = 2 * NX;
+    static constexpr int SCRATCH = (TW + NT + 130 > GUARD * RS) ? TW + NT + 130 : GUARD * RS;
+    // The z solve stages the pivot table (NZ/2+1 rows x NH modes) in LDS that is idle during the projection: rows [0, TSPLIT)
+    // + one junction row (NX reals) over the reduction scratch, the rest + a junction row over the top guard rows; the little
+    // that does not fit there extends the allocation.  TSPLIT is a multiple of the sweeps' prefetch block.
+    static constexpr int TROWS = NZ / 2 + 1, ZBLK = 8;
+    static constexpr int tsplit()
+    {
+        int t = (SCRATCH - TW - NX) / NH / ZBLK * ZBLK;
+        if (t > 16) t = 16;
+        if (t > NZ / 2) t = NZ / 2;
+        return t < 0 ? 0 : t;
+    }
+    static constexpr int TSPLIT = tsplit();
+    static constexpr int ZTAIL = ((TROWS - TSPLIT) * NH + NX > GUARD * RS) ? (TROWS - TSPLIT) * NH + NX - GUARD * RS : 0;
+    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH + 3 * NCELL + GUARD * RS + ZTAIL) * sizeof(T);
     static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
     static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
+    // workgroups that share a CU (LDS and the 2048-thread limit decide) -> waves per SIMD the register allocation must allow
+    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 163840 && 2 * NT <= 2048) ? 2 : 1;
+    static constexpr int WAVES_PER_SIMD = (WG_PER_CU * NT / 64 + 3) / 4;
 };
 
 // Re-derive per-thread indices inside each phase instead of keeping dozens of loop-invariant
@@ -291,29 +360,30 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// position of Fourier mode m inside a transformed row (digit-reversed 8x12 order)
-__device__ __forceinline__ int mode_pos(int m) { return 12 * (m & 7) + (m >> 3); }
+// position of Fourier mode m inside a transformed row (digit-reversed 8 x N2 order)
+template <int N2> __device__ __forceinline__ int mode_pos(int m) { return N2 * (m & 7) + (m >> 3); }
 
-// deterministic block reduction (sum) through LDS scratch; result broadcast to all threads
-template <int NT>
-__device__ inline double block_sum(double v, double *scr, int tid)
+// deterministic block reduction (sum) through LDS scratch (NT + 65 reals); partial sums are stored in the working
+// precision, accumulated in double; result broadcast to all threads
+template <int NT, typename T>
+__device__ inline double block_sum(double v, T *scr, int tid)
 {
     __syncthreads();
-    scr[tid] = v;
+    scr[tid] = (T)v;
     __syncthreads();
     if (tid < 64) {
         double s = 0.0;
-        for (int j = tid; j < NT; j += 64) s += scr[j];
-        scr[NT + tid] = s;
+        for (int j = tid; j < NT; j += 64) s += (double)scr[j];
+        scr[NT + tid] = (T)s;
     }
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
-        for (int j = 0; j < 64; ++j) s += scr[NT + j];
-        scr[NT + 64] = s;
+        for (int j = 0; j < 64; ++j) s += (double)scr[NT + j];
+        scr[NT + 64] = (T)s;
     }
     __syncthreads();
-    return scr[NT + 64];
+    return (double)scr[NT + 64];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -322,14 +392,14 @@ __device__ inline double block_sum(double v, double *scr, int tid)
 // u,w hold the projected velocities (own cells written, not fenced) and the b slot holds phi
 // (its mean is NOT removed).
 // ------------------------------------------------------------------------------------------
-template <int NX, int NZ>
-__device__ __forceinline__ void project(double *__restrict__ lds, const double *__restrict__ tw,
-                                        const double *__restrict__ tri_inv, double dts, double rdx, double rdz,
+template <int NX, int NZ, typename T>
+__device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict__ tw,
+                                        const double *__restrict__ tri_inv, T dts, T rdx, T rdz,
                                         int tid_in, unsigned long long *stamp_acc, unsigned long long &stamp_last,
-                                        double (&un)[CZ], double (&wn)[CZ])
+                                        T (&un)[CZ], T (&wn)[CZ])
 {
-    using G = Geo<NX, NZ>;
-    constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
+    using G = Geo<NX, NZ, T>;
+    constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB, N2 = G::N2;
     (void)stamp_acc; (void)stamp_last;
     int tid = tid_in;
     lds_barrier();
@@ -338,29 +408,29 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     // Stage the pivot table of the z solve (NZ/2+1 rows x NH modes, L2-resident) into LDS that is idle during the
     // projection: rows 0..15 over the reduction scratch (the column-scan partials of this stage are consumed), the
     // rest over the top guard rows (their content is never used).  Loads are issued here, stored after the rhs.
-    constexpr int TROWS = NZ / 2 + 1, TSPLIT = 16, TN = TROWS * G::NH, TPER = (TN + G::NT - 1) / G::NT;
-    static_assert(TSPLIT * G::NH + NX <= SCRATCH_DOUBLES - 192, "pivot rows 0..15 + a junction row must fit the reduction scratch");
+    constexpr int TROWS = G::TROWS, TSPLIT = G::TSPLIT, TN = TROWS * G::NH, TPER = (TN + G::NT - 1) / G::NT;
+    static_assert(TSPLIT * G::NH + NX <= G::SCRATCH - G::TW, "pivot rows [0, TSPLIT) + a junction row must fit the reduction scratch");
     static_assert((TROWS - TSPLIT) * G::NH + NX <= G::GUARD * RS + G::ZTAIL, "remaining pivot rows + a junction row must fit above the fields");
-    double *tabA = const_cast<double *>(tw) + 192;
-    double *tabB = lds + NZ * RS - TSPLIT * G::NH;          // indexed with the global row number
-    double tstage[TPER];
+    T *tabA = const_cast<T *>(tw) + G::TW;
+    T *tabB = lds + NZ * RS - TSPLIT * G::NH;               // indexed with the global row number
+    T tstage[TPER];
 #pragma unroll
-    for (int q = 0; q < TPER; ++q) { const int idx = tid + q * G::NT; tstage[q] = tri_inv[min(idx, TN - 1)]; }
+    for (int q = 0; q < TPER; ++q) { const int idx = tid + q * G::NT; tstage[q] = (T)tri_inv[min(idx, TN - 1)]; }
     // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl).  un/wn = this thread's own U* cells
     // (also in LDS for the neighbours); only the east u and the w face above the chunk are read.
     {
         const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, ip1 = (i + 1 == NX) ? 0 : i + 1;
         const bool top = (c == G::NC - 1);
-        const double rdt = 1.0 / dts;
-        const double *me = lds + k0 * RS;
-        double ue[CZ];
+        const T rdt = T(1) / dts;
+        const T *me = lds + k0 * RS;
+        T ue[CZ];
 #pragma unroll
         for (int r = 0; r < CZ; ++r) ue[r] = me[r * RS + FU + ip1];
-        const double wtop = top ? 0.0 : me[CZ * RS + FW + i];
+        const T wtop = top ? T(0) : me[CZ * RS + FW + i];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < CZ; ++r) {
-            const double whi = (r == CZ - 1) ? wtop : wn[r + 1];
+            const T whi = (r == CZ - 1) ? wtop : wn[r + 1];
             lds[(k0 + r) * RS + FB + i] = ((ue[r] - un[r]) * rdx + (whi - wn[r]) * rdz) * rdt;
         }
     }
@@ -374,35 +444,35 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     tid = opaque(tid_in);
     // ---- forward FFT along x, two rows packed as one complex sequence: row p (real part) with its mirror
     //      image NZ-1-p (imaginary part), see the z solve below ------------------------------------------
-    if (tid < 12 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W96^(n2*k1)
-        const int p = tid / 12, n2 = tid - 12 * p;
-        double *R = lds + p * RS + FB, *I = lds + (NZ - 1 - p) * RS + FB;
-        double re[8], im[8];
+    if (tid < N2 * (NZ / 2)) {          // pass A: DFT-8 over n1 for fixed n2, twiddle W_NX^(n2*k1)
+        const int p = tid / N2, n2 = tid - N2 * p;
+        T *R = lds + p * RS + FB, *I = lds + (NZ - 1 - p) * RS + FB;
+        T re[8], im[8];
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) { re[n1] = R[12 * n1 + n2]; im[n1] = I[12 * n1 + n2]; }
+        for (int n1 = 0; n1 < 8; ++n1) { re[n1] = R[N2 * n1 + n2]; im[n1] = I[N2 * n1 + n2]; }
         dft8(re, im);
 #pragma unroll
         for (int k1 = 1; k1 < 8; ++k1) {
-            const double c = tw[2 * (n2 * 8 + k1)], s = tw[2 * (n2 * 8 + k1) + 1];  // W = c - i s
-            double t = re[k1];
+            const T c = tw[2 * (n2 * 8 + k1)], s = tw[2 * (n2 * 8 + k1) + 1];  // W = c - i s
+            T t = re[k1];
             re[k1] = t * c + im[k1] * s;
             im[k1] = im[k1] * c - t * s;
         }
 #pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) { R[12 * k1 + n2] = re[k1]; I[12 * k1 + n2] = im[k1]; }
+        for (int k1 = 0; k1 < 8; ++k1) { R[N2 * k1 + n2] = re[k1]; I[N2 * k1 + n2] = im[k1]; }
     }
     lds_barrier();
     STAMP(7);
     tid = opaque(tid_in);
-    if (tid < 8 * (NZ / 2)) {           // pass B: DFT-12 over n2 for fixed k1 -> mode k1+8*k2 at 12*k1+k2
+    if (tid < 8 * (NZ / 2)) {           // pass B: DFT-N2 over n2 for fixed k1 -> mode k1+8*k2 at N2*k1+k2
         const int p = tid / 8, k1 = tid - 8 * p;
-        double *R = lds + p * RS + FB + 12 * k1, *I = lds + (NZ - 1 - p) * RS + FB + 12 * k1;
-        double re[12], im[12];
+        T *R = lds + p * RS + FB + N2 * k1, *I = lds + (NZ - 1 - p) * RS + FB + N2 * k1;
+        T re[N2], im[N2];
 #pragma unroll
-        for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
-        dft12(re, im);
+        for (int n = 0; n < N2; ++n) { re[n] = R[n]; im[n] = I[n]; }
+        dft_n2<N2>(re, im);
 #pragma unroll
-        for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
+        for (int n = 0; n < N2; ++n) { R[n] = re[n]; I[n] = im[n]; }
     }
     lds_barrier();
     STAMP(8);
@@ -421,27 +491,28 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     //     downward (the operator is mirror symmetric, so both use the same pivots), they meet in a
     //     2x2 junction and substitute back outward.  y/x overwrite the column in place.
     constexpr int HALF = NZ / 2;
-    const bool sw_up = tid < NX, sw_dn = (tid >= 128) && (tid < 128 + NX);
-    const int tj = sw_up ? tid : tid - 128;
+    constexpr int NXP = G::NXP;
+    const bool sw_up = tid < NX, sw_dn = (tid >= NXP) && (tid < NXP + NX);
+    const int tj = sw_up ? tid : tid - NXP;
     const int tm = min(tj, NX - tj);
-    const double cpf = rdz * rdz * (double)NX;                // cp_k = tab_k * cpf
+    const T cpf = rdz * rdz * (T)NX;                // cp_k = tab_k * cpf
     const int tp = (tj == 0) ? 0 : NX - tj;                   // junction partner column (mode NX-m)
-    double *colb = lds + FB + mode_pos(tj);
-    double *jctA = tabA + TSPLIT * G::NH, *jctB = tabB + TROWS * G::NH;
+    T *colb = lds + FB + mode_pos<N2>(tj);
+    T *jctA = tabA + TSPLIT * G::NH, *jctB = tabB + TROWS * G::NH;
     // Both sweeps are written with the direction as a compile-time constant and fully unrolled, so every LDS
     // access is base + immediate and a row costs two loads, two fp64 ops and a store: the four active waves
     // sit alone on their SIMDs and the phase is bound by their instruction count.
-    constexpr int BLK = 8;                                     // rows fetched ahead of the recurrence
+    constexpr int BLK = G::ZBLK;                               // rows fetched ahead of the recurrence
     static_assert(HALF % BLK == 0 && TSPLIT % BLK == 0, "z-sweep blocks must not straddle the table split");
     auto fwd = [&](auto dir) {
         constexpr int DIR = decltype(dir)::value;
-        double y = 0.0;
-        double rr[BLK], tt[BLK];
+        T y = T(0);
+        T rr[BLK], tt[BLK];
 #pragma unroll
-        for (int j = 0; j < BLK; ++j) { rr[j] = colb[(DIR > 0 ? j : NZ - 1 - j) * RS]; tt[j] = tabA[j * G::NH + tm]; }
+        for (int j = 0; j < BLK; ++j) { rr[j] = colb[(DIR > 0 ? j : NZ - 1 - j) * RS]; tt[j] = (j < TSPLIT ? tabA : tabB)[j * G::NH + tm]; }
 #pragma unroll
         for (int s0 = 0; s0 < HALF; s0 += BLK) {
-            double rn[BLK], tn[BLK];
+            T rn[BLK], tn[BLK];
             if (s0 + BLK < HALF) {
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {
@@ -462,20 +533,20 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         }
         (DIR > 0 ? jctA : jctB)[tj] = y;       // junction values travel through side rows: the other sweep overwrites in place
     };
-    if (tid < 128) { if (sw_up) fwd(std::integral_constant<int, 1>{}); }
-    else if (tid < 256) { if (sw_dn) fwd(std::integral_constant<int, -1>{}); }
+    if (tid < NXP) { if (sw_up) fwd(std::integral_constant<int, 1>{}); }
+    else if (tid < 2 * NXP) { if (sw_dn) fwd(std::integral_constant<int, -1>{}); }
     lds_barrier();
     STAMP(17);
     auto bwd = [&](auto dir) {
         constexpr int DIR = decltype(dir)::value;
-        const double ya = DIR > 0 ? jctA[tj] : jctA[tp], yb = DIR > 0 ? jctB[tp] : jctB[tj];
-        const double c = (HALF - 1 < TSPLIT ? tabA : tabB)[(HALF - 1) * G::NH + tm] * cpf;
-        const double jf = (HALF < TSPLIT ? tabA : tabB)[HALF * G::NH + tm];   // 1/(1-c^2); 0 for the singular mean mode
-        double x = DIR > 0 ? (ya - c * yb) * jf : (yb - c * ya) * jf;
-        if (tm == 0) x = DIR > 0 ? ya : 0.0;                                  // pin the mean mode (mean removed on output)
+        const T ya = DIR > 0 ? jctA[tj] : jctA[tp], yb = DIR > 0 ? jctB[tp] : jctB[tj];
+        const T c = (HALF - 1 < TSPLIT ? tabA : tabB)[(HALF - 1) * G::NH + tm] * cpf;
+        const T jf = (HALF < TSPLIT ? tabA : tabB)[HALF * G::NH + tm];   // 1/(1-c^2); 0 for the singular mean mode
+        T x = DIR > 0 ? (ya - c * yb) * jf : (yb - c * ya) * jf;
+        if (tm == 0) x = DIR > 0 ? ya : T(0);                                  // pin the mean mode (mean removed on output)
         colb[(DIR > 0 ? HALF - 1 : HALF) * RS] = x;
         // rows HALF-2 .. 0 (sweep-local numbering), fetched BLK ahead; the first block is one row short
-        double yy[BLK], cc[BLK];
+        T yy[BLK], cc[BLK];
 #pragma unroll
         for (int j = 0; j < BLK; ++j) {
             const int sidx = HALF - 2 - j;
@@ -484,7 +555,7 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
         }
 #pragma unroll
         for (int s0 = HALF - 2; s0 >= 0; s0 -= BLK) {
-            double yn[BLK], cn[BLK];
+            T yn[BLK], cn[BLK];
 #pragma unroll
             for (int j = 0; j < BLK; ++j) {
                 const int sidx = s0 - BLK - j;
@@ -505,42 +576,42 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
             for (int j = 0; j < BLK; ++j) { yy[j] = yn[j]; cc[j] = cn[j]; }
         }
     };
-    if (tid < 128) { if (sw_up) bwd(std::integral_constant<int, 1>{}); }
-    else if (tid < 256) { if (sw_dn) bwd(std::integral_constant<int, -1>{}); }
+    if (tid < NXP) { if (sw_up) bwd(std::integral_constant<int, 1>{}); }
+    else if (tid < 2 * NXP) { if (sw_dn) bwd(std::integral_constant<int, -1>{}); }
     lds_barrier();
     STAMP(18);
     tid = opaque(tid_in);
     // ---- inverse FFT (swap re<->im roles) --------------------------------------------------
     if (tid < 8 * (NZ / 2)) {
         const int p = tid / 8, k1 = tid - 8 * p;
-        double *R = lds + p * RS + FB + 12 * k1, *I = lds + (NZ - 1 - p) * RS + FB + 12 * k1;
-        double re[12], im[12];
+        T *R = lds + p * RS + FB + N2 * k1, *I = lds + (NZ - 1 - p) * RS + FB + N2 * k1;
+        T re[N2], im[N2];
 #pragma unroll
-        for (int n = 0; n < 12; ++n) { re[n] = R[n]; im[n] = I[n]; }
-        dft12(im, re);
-        // inverse twiddle W96^(-n2*k1): (a+ib)(c+is)
+        for (int n = 0; n < N2; ++n) { re[n] = R[n]; im[n] = I[n]; }
+        dft_n2<N2>(im, re);
+        // inverse twiddle W_NX^(-n2*k1): (a+ib)(c+is)
 #pragma unroll
-        for (int n2 = 1; n2 < 12; ++n2) {
-            const double c = tw[2 * (n2 * 8 + k1)], s = tw[2 * (n2 * 8 + k1) + 1];
-            double t = re[n2];
+        for (int n2 = 1; n2 < N2; ++n2) {
+            const T c = tw[2 * (n2 * 8 + k1)], s = tw[2 * (n2 * 8 + k1) + 1];
+            T t = re[n2];
             re[n2] = t * c - im[n2] * s;
             im[n2] = im[n2] * c + t * s;
         }
 #pragma unroll
-        for (int n = 0; n < 12; ++n) { R[n] = re[n]; I[n] = im[n]; }
+        for (int n = 0; n < N2; ++n) { R[n] = re[n]; I[n] = im[n]; }
     }
     lds_barrier();
     STAMP(10);
     tid = opaque(tid_in);
-    if (tid < 12 * (NZ / 2)) {
-        const int p = tid / 12, n2 = tid - 12 * p;
-        double *R = lds + p * RS + FB, *I = lds + (NZ - 1 - p) * RS + FB;
-        double re[8], im[8];
+    if (tid < N2 * (NZ / 2)) {
+        const int p = tid / N2, n2 = tid - N2 * p;
+        T *R = lds + p * RS + FB, *I = lds + (NZ - 1 - p) * RS + FB;
+        T re[8], im[8];
 #pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) { re[k1] = R[12 * k1 + n2]; im[k1] = I[12 * k1 + n2]; }
+        for (int k1 = 0; k1 < 8; ++k1) { re[k1] = R[N2 * k1 + n2]; im[k1] = I[N2 * k1 + n2]; }
         dft8(im, re);
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) { R[12 * n1 + n2] = re[n1]; I[12 * n1 + n2] = im[n1]; }
+        for (int n1 = 0; n1 < 8; ++n1) { R[N2 * n1 + n2] = re[n1]; I[N2 * n1 + n2] = im[n1]; }
     }
     lds_barrier();
     STAMP(11);
@@ -548,11 +619,11 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
     // ---- pressure_correct_velocities! ([OC] pressure_correction.jl) -------------------------
     {
         const int c = tid / NX, i = tid - c * NX, k0 = c * CZ, im1 = (i == 0) ? NX - 1 : i - 1;
-        double *me = lds + k0 * RS;
-        double pc[CZ], pw[CZ];
+        T *me = lds + k0 * RS;
+        T pc[CZ], pw[CZ];
 #pragma unroll
         for (int r = 0; r < CZ; ++r) { pc[r] = me[r * RS + FB + i]; pw[r] = me[r * RS + FB + im1]; }
-        double pdn = (k0 > 0) ? me[-RS + FB + i] : 0.0;
+        T pdn = (k0 > 0) ? me[-RS + FB + i] : T(0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < CZ; ++r) {
@@ -568,16 +639,18 @@ __device__ __forceinline__ void project(double *__restrict__ lds, const double *
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-template <int NX, int NZ>
-__global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
+template <int NX, int NZ, typename T>
+__global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) void rbc2d_kernel(const Params2D P)
 {
-    using G = Geo<NX, NZ>;
-    constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB;
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    double *Sc = lds_raw;
-    double *lds = lds_raw + SCRATCH_DOUBLES;   // field rows start here
-    double *tw = Sc;                 // [12][8][2] twiddles c,s of W96^(n2*k1) = c - i s
-    double *scr = Sc + 192;          // reductions / column-scan partials (NT + 130 doubles)
+    using G = Geo<NX, NZ, T>;
+    typedef T real;                  // working precision: real (the reference's Float64) or float (the fp32 variant)
+    constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB, N2 = G::N2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_bytes_raw[];
+    real *lds_raw = reinterpret_cast<real *>(lds_bytes_raw);
+    real *Sc = lds_raw;
+    real *lds = lds_raw + G::SCRATCH;   // field rows start here
+    real *tw = Sc;                   // [N2][8][2] twiddles c,s of W_NX^(n2*k1) = c - i s
+    real *scr = Sc + G::TW;          // reductions / column-scan partials (NT + 130 reals)
 
     const int env = blockIdx.x;
     if (P.mask && !P.mask[env]) return;
@@ -591,22 +664,24 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     const int k0 = c * CZ;
     const bool top = (c == G::NC - 1);
 
-    const double dx = P.dx, dz = P.dz, rdx = P.rdx, rdz = P.rdz;
-    const double nu = P.nu_kappa[2 * env], kap = P.nu_kappa[2 * env + 1];
+    const real dx = (real)P.dx, dz = (real)P.dz, rdx = (real)P.rdx, rdz = (real)P.rdz, rdx2 = (real)rdx2, rdz2 = (real)rdz2;
+    const real min_b = (real)P.min_b;
+    const real nu = (real)P.nu_kappa[2 * env], kap = (real)P.nu_kappa[2 * env + 1];
 
-    if (tid < 96) {
+    if (tid < NX) {                  // N2 * 8 = NX twiddles
         const int n2 = tid / 8, k1 = tid - 8 * n2;
         double s, cc;
         sincospi(2.0 * (double)(n2 * k1) / (double)NX, &s, &cc);
-        tw[2 * tid] = cc; tw[2 * tid + 1] = s;
+        tw[2 * tid] = (real)cc; tw[2 * tid + 1] = (real)s;
     }
 
     double *gf = P.fields + (size_t)env * G::ENV_STRIDE;
     double *gb_ = gf, *gu_ = gf + G::NCELL, *gw_ = gf + 2 * G::NCELL;
 
     // ---- A10: heater profile of this column (collate_actions_colin, rbc_sim2D.jl:87-133) ----
-    double Tb;
+    real Tb;
     {
+        double Tbd;
         const int n = P.heaters;
         const double ampl = P.heater_limit, hdx = 0.03;
         const bool zero_action = (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM || P.actions == nullptr);
@@ -625,33 +700,34 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         const double T1 = 2 + (ampl * (act ? (double)act[xs - 1] : 0.0) - mean) / K2;
         const double T2 = 2 + (ampl * (act ? (double)act[a2 - 1] : 0.0) - mean) / K2;
         const double xp = x - (xs - 1) * seg;
-        if (xp < hdx) Tb = T0 + ((T0 - T1) / (4 * hdx * hdx * hdx)) * (xp - 2 * hdx) * (xp + hdx) * (xp + hdx);
-        else if (xp >= seg - hdx) Tb = T1 + ((T1 - T2) / (4 * hdx * hdx * hdx)) * (xp - seg - 2 * hdx) * (xp - seg + hdx) * (xp - seg + hdx);
-        else Tb = T1;
+        if (xp < hdx) Tbd = T0 + ((T0 - T1) / (4 * hdx * hdx * hdx)) * (xp - 2 * hdx) * (xp + hdx) * (xp + hdx);
+        else if (xp >= seg - hdx) Tbd = T1 + ((T1 - T2) / (4 * hdx * hdx * hdx)) * (xp - seg - 2 * hdx) * (xp - seg + hdx) * (xp - seg + hdx);
+        else Tbd = T1;
+        Tb = (real)Tbd;
     }
 
     // ---- load (or generate) the state of the own cells --------------------------------------
-    double bn[CZ];
+    real bn[CZ];
     {
-        double *me = lds + k0 * RS + i;
+        real *me = lds + k0 * RS + i;
         if (P.mode == MODE_RANDOM) {   // initialize_model, rbc_sim2D.jl:163-171
             const uint64_t seed = P.seeds[env];
             for (int r = 0; r < CZ; ++r) {
                 const int k = k0 + r;
                 const uint32_t id = (uint32_t)(k * NX + i);
-                me[r * RS + FU] = P.kick * normal_deviate(seed, 0, id);
-                me[r * RS + FW] = (k == 0) ? 0.0 : P.kick * normal_deviate(seed, 1, id);
-                const double z = (k + 0.5) * dz;
+                me[r * RS + FU] = (real)(P.kick * normal_deviate(seed, 0, id));
+                me[r * RS + FW] = (k == 0) ? real(0) : (real)(P.kick * normal_deviate(seed, 1, id));
+                const double z = (k + 0.5) * P.dz;
                 const double v = P.min_b + (P.lz - z) * P.delta_b / 2 + P.kick * normal_deviate(seed, 2, id);
-                me[r * RS + FB] = fmin(fmax(v, P.min_b), P.min_b + P.delta_b);
+                me[r * RS + FB] = (real)fmin(fmax(v, P.min_b), P.min_b + P.delta_b);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < CZ; ++r) {
                 const int k = k0 + r;
-                me[r * RS + FB] = gb_[k * NX + i];
-                me[r * RS + FU] = gu_[k * NX + i];
-                me[r * RS + FW] = (k == 0) ? 0.0 : gw_[k * NX + i];
+                me[r * RS + FB] = (real)gb_[k * NX + i];
+                me[r * RS + FU] = (real)gu_[k * NX + i];
+                me[r * RS + FW] = (k == 0) ? real(0) : (real)gw_[k * NX + i];
             }
         }
 #pragma unroll
@@ -663,23 +739,24 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     // per thread, a wave covers 4 KiB contiguously) and fetched back one pass ahead of their use, so
     // their load latency hides under the preceding pass and the Poisson phases run with 32 fewer
     // live VGPRs.
-    double g0u[CZ];
+    real g0u[CZ];
 #pragma unroll
-    for (int r = 0; r < CZ; ++r) g0u[r] = 0.0;
-    typedef double dbl2 __attribute__((ext_vector_type(2)));
-    dbl2 *park_b = reinterpret_cast<dbl2 *>(P.gpark + (((size_t)env * 2 + 0) * G::NT + tid) * CZ);
-    dbl2 *park_w = reinterpret_cast<dbl2 *>(P.gpark + (((size_t)env * 2 + 1) * G::NT + tid) * CZ);
+    for (int r = 0; r < CZ; ++r) g0u[r] = real(0);
+    typedef real dbl2 __attribute__((ext_vector_type(2)));
+    real *gpark = reinterpret_cast<real *>(P.gpark);       // the workspace holds the working precision
+    dbl2 *park_b = reinterpret_cast<dbl2 *>(gpark + (((size_t)env * 2 + 0) * G::NT + tid) * CZ);
+    dbl2 *park_w = reinterpret_cast<dbl2 *>(gpark + (((size_t)env * 2 + 1) * G::NT + tid) * CZ);
 
-    const double rhz = P.rhz;   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
+    const real rhz = (real)P.rhz;   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
     const int nstage = (P.mode == MODE_STEP) ? 3 * P.nsub : ((P.mode == MODE_TENDENCY) ? 1 : 0);
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
         // set!'s incompressibility projection with unit time step ([OC] set_nonhydrostatic_model.jl)
-        double u0[CZ], w0[CZ];
+        real u0[CZ], w0[CZ];
         lds_barrier();
 #pragma unroll
         for (int r = 0; r < CZ; ++r) { u0[r] = lds[(k0 + r) * RS + FU + i]; w0[r] = lds[(k0 + r) * RS + FW + i]; }
-        project<NX, NZ>(lds, tw, P.tri_inv, 1.0, rdx, rdz, tid, stamp_acc, stamp_last, u0, w0);
+        project<NX, NZ, T>(lds, tw, P.tri_inv, real(1), rdx, rdz, tid, stamp_acc, stamp_last, u0, w0);
         // the b slot now holds phi (pNHS); b stays in registers
     } else {
         lds_barrier();
@@ -694,11 +771,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     STAMP(0);
     for (int st = 0; st < nstage; ++st) {
         const int sub = st / 3, ph = st - 3 * sub;
-        const double dt = (sub == P.nsub - 1) ? P.dt_last : P.dt;
+        const real dt = (real)((sub == P.nsub - 1) ? P.dt_last : P.dt);
         // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl)
-        const double gam = (ph == 0) ? 8.0 / 15.0 : (ph == 1 ? 5.0 / 12.0 : 3.0 / 4.0);
-        const double zet = (ph == 0) ? 0.0 : (ph == 1 ? -17.0 / 60.0 : -5.0 / 12.0);
-        const double dts = (gam + zet) * dt;
+        const real gam = (ph == 0) ? real(8.0 / 15.0) : (ph == 1 ? real(5.0 / 12.0) : real(3.0 / 4.0));
+        const real zet = (ph == 0) ? real(0.0) : (ph == 1 ? real(-17.0 / 60.0) : real(-5.0 / 12.0));
+        const real dts = (gam + zet) * dt;
         const bool dbg = (P.mode == MODE_TENDENCY);
         double *dg = dbg ? P.dbg_g + (size_t)env * 3 * G::NCELL : nullptr;
         STAMP(14);
@@ -708,13 +785,13 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         const int c = ti / NX, i = ti - c * NX, k0 = c * CZ;
         const int ip1 = (i + 1 == NX) ? 0 : i + 1, ip2 = (ip1 + 1 == NX) ? 0 : ip1 + 1, ip3 = (ip2 + 1 == NX) ? 0 : ip2 + 1;
         const int im1 = (i == 0) ? NX - 1 : i - 1, im2 = (im1 == 0) ? NX - 1 : im1 - 1, im3 = (im2 == 0) ? NX - 1 : im2 - 1;
-        const double *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
-        const double *cc0 = lds + k0 * RS + i;
-        const double *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
+        const real *cm3 = lds + k0 * RS + im3, *cm2 = lds + k0 * RS + im2, *cm1 = lds + k0 * RS + im1;
+        const real *cc0 = lds + k0 * RS + i;
+        const real *cp1 = lds + k0 * RS + ip1, *cp2 = lds + k0 * RS + ip2, *cp3 = lds + k0 * RS + ip3;
 
         const bool use_g0 = (ph != 0);      // zeta^1 = 0: the first stage of a substep needs no G^-
         const bool keep_g = (ph != 2);      // the tendencies of the last stage are never reused
-        double un[CZ], wn[CZ];
+        real un[CZ], wn[CZ];
         // The three tendency passes exist twice: waves whose threads all sit in interior chunks (8 of the 12 at
         // NZ=64, two per SIMD) run a copy in which bot/top are compile-time false, i.e. without the 3rd/1st-order
         // fallbacks, wall selects and halo rows.  Both copies execute the same barriers.
@@ -725,92 +802,92 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             // pHY'[k] = pHY'[k+1] - b_face(k+1) dz.  G_u needs pHY'[i,k]-pHY'[i-1,k]
             //         = -dz * sum_{k'>=k} mean(db[k'], db[k'+1]),  db[k] = b[i,k]-b[i-1,k].
             // Pre-pass: the chunk totals; the u pass below walks DOWN its chunk and accumulates.
-            double db_top;   // db at the first row above the chunk (halo row for the top chunk)
+            real db_top;   // db at the first row above the chunk (halo row for the top chunk)
             {
                 {   // branch-free: the top chunk takes the Value-BC halo row, the others the row above
-                    const double cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
-                    const double hN = cN + ((P.min_b - cN) * rhz) * dz, hM = cM + ((P.min_b - cM) * rhz) * dz;
-                    const double dn = cc0[off(CZ, FB)] - cm1[off(CZ, FB)];
+                    const real cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
+                    const real hN = cN + ((min_b - cN) * rhz) * dz, hM = cM + ((min_b - cM) * rhz) * dz;
+                    const real dn = cc0[off(CZ, FB)] - cm1[off(CZ, FB)];
                     db_top = top ? (hN - hM) : dn;
                 }
-                double acc = 0.0, dbu = db_top;
-                double dcol[CZ], dmin[CZ];       // all loads first: hipcc otherwise serialises eight LDS round trips
+                real acc = real(0), dbu = db_top;
+                real dcol[CZ], dmin[CZ];       // all loads first: hipcc otherwise serialises eight LDS round trips
 #pragma unroll
                 for (int r = 0; r < CZ; ++r) { dcol[r] = cc0[r * RS + FB]; dmin[r] = cm1[r * RS + FB]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = CZ - 1; r >= 0; --r) {
-                    const double d = dcol[r] - dmin[r];
-                    acc += 0.5 * (d + dbu);
+                    const real d = dcol[r] - dmin[r];
+                    acc += real(0.5) * (d + dbu);
                     dbu = d;
                 }
                 scr[c * NX + i] = acc;
             }
             STAMP(15);
-            double g0b[CZ], g0w[CZ];
+            real g0b[CZ], g0w[CZ];
             lds_barrier();
             STAMP(1);
 #pragma unroll
             for (int r = 0; r < CZ; r += 2) {                                         // lands under the u pass
-                dbl2 v; v.x = 0.0; v.y = 0.0;
+                dbl2 v; v.x = real(0); v.y = real(0);
                 if (use_g0) v = park_b[r / 2];                                        // uniform branch: zeta^1 = 0 needs no G^-
                 g0b[r] = v.x; g0b[r + 1] = v.y;
             }
             __builtin_amdgcn_s_setprio(WALL ? RBC_PU_W : RBC_PU_I);      // waves still in an earlier pass outrank those ahead of them
             // ======================= u tendency (walks down the chunk) ==============================
             {
-                double above = 0.0;
+                real above = real(0);
                 for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
-                double pacc = 0.0, dbu = db_top;
+                real pacc = real(0), dbu = db_top;
                 // z window of u around face k+1: rows k-2..k+3  (w0..w5), face between w2|w3
-                double w0, w1, w2, w3, w4, w5;
+                real w0, w1, w2, w3, w4, w5;
                 w0 = cc0[off(CZ - 3, FU)]; w1 = cc0[off(CZ - 2, FU)]; w2 = cc0[off(CZ - 1, FU)];
                 w3 = cc0[off(CZ, FU)]; w4 = cc0[off(CZ + 1, FU)]; w5 = cc0[off(CZ + 2, FU)];
                 // top face of the chunk (face k0+CZ): advecting w in x (Centered(4), periodic)
-                double wm_hi, wc_hi, fz_hi, uup;
+                real wm_hi, wc_hi, fz_hi, uup;
                 {   // branch-free (clamped loads, selects): the top wall face carries no flux and w=0
-                    wm_hi = top ? 0.0 : cm1[off(CZ, FW)]; wc_hi = top ? 0.0 : cc0[off(CZ, FW)];
-                    const double wt = sym4(cm2[off(CZ, FW)], wm_hi, wc_hi, cp1[off(CZ, FW)]);
-                    const double f = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
-                    fz_hi = top ? 0.0 : f;
-                    uup = top ? (w2 + ((0.0 - w2) * rhz) * dz) : w3;   // halo row above the top cell
+                    wm_hi = top ? real(0) : cm1[off(CZ, FW)]; wc_hi = top ? real(0) : cc0[off(CZ, FW)];
+                    const real wt = sym4(cm2[off(CZ, FW)], wm_hi, wc_hi, cp1[off(CZ, FW)]);
+                    const real f = upwz(wt, w0, w1, w2, w3, w4, w5, true, true);
+                    fz_hi = top ? real(0) : f;
+                    uup = top ? (w2 + ((real(0) - w2) * rhz) * dz) : w3;   // halo row above the top cell
                 }
 #pragma unroll
                 for (int r = CZ - 1; r >= 0; --r) {
                     // slide the window down: now around face k (rows k-3..k+2)
                     w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = w0; w0 = cc0[off(r - 3, FU)];
-                    const double u0 = w3;
-                    const double um3 = cm3[r * RS + FU], um2 = cm2[r * RS + FU], um1 = cm1[r * RS + FU];
-                    const double up1 = cp1[r * RS + FU], up2 = cp2[r * RS + FU], up3 = cp3[r * RS + FU];
+                    const real u0 = w3;
+                    const real um3 = cm3[r * RS + FU], um2 = cm2[r * RS + FU], um1 = cm1[r * RS + FU];
+                    const real up1 = cp1[r * RS + FU], up2 = cp2[r * RS + FU], up3 = cp3[r * RS + FU];
                     // flux_uu at centres i-1 and i  (advective_momentum_flux_Uu)
-                    const double ut_w = sym4(um2, um1, u0, up1);
-                    const double ut_e = sym4(um1, u0, up1, up2);
-                    const double fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
-                    const double fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
+                    const real ut_w = sym4(um2, um1, u0, up1);
+                    const real ut_e = sym4(um1, u0, up1, up2);
+                    const real fx_w = upw5(ut_w, um3, um2, um1, u0, up1, up2);
+                    const real fx_e = upw5(ut_e, um2, um1, u0, up1, up2, up3);
                     // bottom face k of this cell
-                    double fz_lo, udn, wm_lo, wc_lo;
+                    real fz_lo, udn, wm_lo, wc_lo;
                     {   // the bottom wall row of w is identically 0 in LDS, so its flux vanishes by itself
                         wm_lo = cm1[r * RS + FW]; wc_lo = cc0[r * RS + FW];
-                        const double wt = sym4(cm2[r * RS + FW], wm_lo, wc_lo, cp1[r * RS + FW]);
+                        const real wt = sym4(cm2[r * RS + FW], wm_lo, wc_lo, cp1[r * RS + FW]);
                         // face k: 5th if 3<=k<=NZ-3, 3rd if 2<=k<=NZ-2, else 1st
                         const bool ok5 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);
                         const bool ok3 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);
                         fz_lo = upwz(wt, w0, w1, w2, w3, w4, w5, ok5, ok3);
                         const bool wall = (r == 0) && bot;
-                        fz_lo = wall ? 0.0 : fz_lo;
-                        udn = wall ? (u0 + ((u0 - 0.0) * rhz) * (-dz)) : w2;
+                        fz_lo = wall ? real(0) : fz_lo;
+                        udn = wall ? (u0 + ((u0 - real(0)) * rhz) * (-dz)) : w2;
                     }
-                    const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                    const real adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
                     // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures, isotropic ScalarDiffusivity)
-                    const double vis = nu * (2.0 * ((up1 - u0) - (u0 - um1)) * P.rdx2
+                    const real vis = nu * (real(2) * ((up1 - u0) - (u0 - um1)) * rdx2
                                              + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
                     // hydrostatic pressure gradient
-                    const double d = cc0[r * RS + FB] - cm1[r * RS + FB];
-                    pacc += 0.5 * (d + dbu);
+                    const real d = cc0[r * RS + FB] - cm1[r * RS + FB];
+                    pacc += real(0.5) * (d + dbu);
                     dbu = d;
-                    const double dphy = -(pacc + above) * dz;
-                    const double g = vis - adv - dphy * rdx;
-                    if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = g;
+                    const real dphy = -(pacc + above) * dz;
+                    const real g = vis - adv - dphy * rdx;
+                    if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = (double)g;
     #if RBC_EXPERIMENT_NOG0
                     un[r] = u0 + dt * (gam * g);
     #else
@@ -827,38 +904,38 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             // ======================= b tendency (walks up) ===========================================
 #pragma unroll
             for (int r = 0; r < CZ; r += 2) {                                         // lands under the b pass
-                dbl2 v; v.x = 0.0; v.y = 0.0;
+                dbl2 v; v.x = real(0); v.y = real(0);
                 if (use_g0) v = park_w[r / 2];
                 g0w[r] = v.x; g0w[r + 1] = v.y;
             }
             {
-                double w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
+                real w0, w1, w2, w3, w4, w5;   // b rows k-3..k+2 around face k (face between w2|w3)
                 w0 = cc0[off(-3, FB)]; w1 = cc0[off(-2, FB)]; w2 = cc0[off(-1, FB)];
                 w3 = cc0[off(0, FB)]; w4 = cc0[off(1, FB)]; w5 = cc0[off(2, FB)];
-                double fz_lo = bot ? 0.0 : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
-                double bdn = bot ? (w3 + ((w3 - Tb) * rhz) * (-dz)) : w2;      // Value BC halo below the first cell
+                real fz_lo = bot ? real(0) : upwz(cc0[FW], w0, w1, w2, w3, w4, w5, true, true);
+                real bdn = bot ? (w3 + ((w3 - Tb) * rhz) * (-dz)) : w2;      // Value BC halo below the first cell
 #pragma unroll
                 for (int r = 0; r < CZ; ++r) {
                     w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = cc0[off(r + 3, FB)];   // now around face k+1
-                    const double b0 = w2;
-                    const double bm3 = cm3[r * RS + FB], bm2 = cm2[r * RS + FB], bm1 = cm1[r * RS + FB];
-                    const double bp1 = cp1[r * RS + FB], bp2 = cp2[r * RS + FB], bp3 = cp3[r * RS + FB];
-                    const double ui = cc0[r * RS + FU], ue = cp1[r * RS + FU];
-                    const double fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
-                    const double fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
-                    double fz_hi, bup;
+                    const real b0 = w2;
+                    const real bm3 = cm3[r * RS + FB], bm2 = cm2[r * RS + FB], bm1 = cm1[r * RS + FB];
+                    const real bp1 = cp1[r * RS + FB], bp2 = cp2[r * RS + FB], bp3 = cp3[r * RS + FB];
+                    const real ui = cc0[r * RS + FU], ue = cp1[r * RS + FU];
+                    const real fx_i = upw5(ui, bm3, bm2, bm1, b0, bp1, bp2);
+                    const real fx_e = upw5(ue, bm2, bm1, b0, bp1, bp2, bp3);
+                    real fz_hi, bup;
                     {
                         const bool ok5 = ((r + 1 >= 3) || !bot) && ((r + 1 <= CZ - 3) || !top);
                         const bool ok3 = ((r + 1 >= 2) || !bot) && ((r + 1 <= CZ - 2) || !top);
                         const bool wall = (r == CZ - 1) && top;
                         fz_hi = upwz(cc0[off(r + 1, FW)], w0, w1, w2, w3, w4, w5, ok5, ok3);
-                        fz_hi = wall ? 0.0 : fz_hi;
-                        bup = wall ? (b0 + ((P.min_b - b0) * rhz) * dz) : w3;
+                        fz_hi = wall ? real(0) : fz_hi;
+                        bup = wall ? (b0 + ((min_b - b0) * rhz) * dz) : w3;
                     }
-                    const double adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
-                    const double dif = kap * (((bp1 - b0) - (b0 - bm1)) * P.rdx2 + ((bup - b0) - (b0 - bdn)) * P.rdz2);
-                    const double g = dif - adv;
-                    if (dbg) dg[(k0 + r) * NX + i] = g;
+                    const real adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
+                    const real dif = kap * (((bp1 - b0) - (b0 - bm1)) * rdx2 + ((bup - b0) - (b0 - bdn)) * rdz2);
+                    const real g = dif - adv;
+                    if (dbg) dg[(k0 + r) * NX + i] = (double)g;
     #if RBC_EXPERIMENT_NOG0
                     bn[r] = b0 + dt * (gam * g);
     #else
@@ -879,21 +956,21 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                 // every thread has finished reading the old b: its slot now parks the new u so that the
                 // heaviest pass below runs with one new-value array fewer in registers
                 lds_barrier();
-                double *me = lds + k0 * RS + i;
+                real *me = lds + k0 * RS + i;
 #pragma unroll
                 for (int r = 0; r < CZ; ++r) me[r * RS + FB] = un[r];
             }
             __builtin_amdgcn_s_setprio(WALL ? RBC_PW_W : RBC_PW_I);
             // ======================= w tendency (faces k0..k0+7, walks up) ===========================
             {
-                auto wld = [&](int rr) -> double { return (WALL && k0 + rr >= NZ) ? 0.0 : cc0[off(rr, FW)]; };
-                double w0, w1, w2, w3, w4, w5;   // w faces k-2..k+3 around centre k (between w2|w3)
+                auto wld = [&](int rr) -> real { return (WALL && k0 + rr >= NZ) ? real(0) : cc0[off(rr, FW)]; };
+                real w0, w1, w2, w3, w4, w5;   // w faces k-2..k+3 around centre k (between w2|w3)
                 w0 = wld(-3); w1 = wld(-2); w2 = wld(-1); w3 = wld(0); w4 = wld(1); w5 = wld(2);   // centre k0-1
-                double fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);   // flux_ww at centre k0-1
-                fz_lo = bot ? 0.0 : fz_lo;
+                real fz_lo = upwz(sym4(w1, w2, w3, w4), w0, w1, w2, w3, w4, w5, true, true);   // flux_ww at centre k0-1
+                fz_lo = bot ? real(0) : fz_lo;
                 // u columns at x-faces i and i+1: rows k-2..k+1 around z-face k
-                double a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
-                double e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
+                real a0 = cc0[off(-2, FU)], a1 = cc0[off(-1, FU)], a2 = cc0[off(0, FU)], a3 = cc0[off(1, FU)];
+                real e0 = cp1[off(-2, FU)], e1 = cp1[off(-1, FU)], e2 = cp1[off(0, FU)], e3 = cp1[off(1, FU)];
 #pragma unroll
                 for (int r = 0; r < CZ; ++r) {
                     if (r > 0) {
@@ -901,7 +978,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
                         e0 = e1; e1 = e2; e2 = e3; e3 = cp1[off(r + 1, FU)];
                     }
                     w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = wld(r + 3);   // centre k: faces k-2..k+3
-                    const double wc = w2;          // w at face k
+                    const real wc = w2;          // w at face k
                     // flux_ww at centre k: 5th if 2<=k<=NZ-3, 3rd if 1<=k<=NZ-2, else 1st
                     const bool c5 = ((r >= 2) || !bot) && ((r <= CZ - 3) || !top);
                     const bool c3 = ((r >= 1) || !bot) && ((r <= CZ - 2) || !top);
@@ -910,26 +987,26 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     #else
                     const bool c4 = c5;
     #endif
-                    const double fz_hi = upwz(symz(w1, w2, w3, w4, c4), w0, w1, w2, w3, w4, w5, c5, c3);
-                    double g;
+                    const real fz_hi = upwz(symz(w1, w2, w3, w4, c4), w0, w1, w2, w3, w4, w5, c5, c3);
+                    real g;
                     {
     #if RBC_SYMLEVEL
                         const bool f4 = ((r >= 2) || !bot) && ((r <= CZ - 2) || !top);       // 2<=k<=NZ-2
     #else
                         const bool f4 = ((r >= 3) || !bot) && ((r <= CZ - 3) || !top);       // 3<=k<=NZ-3
     #endif
-                        const double ut_w = symz(a0, a1, a2, a3, f4);
-                        const double ut_e = symz(e0, e1, e2, e3, f4);
-                        const double wm3 = cm3[r * RS + FW], wm2 = cm2[r * RS + FW], wm1 = cm1[r * RS + FW];
-                        const double wp1 = cp1[r * RS + FW], wp2 = cp2[r * RS + FW], wp3 = cp3[r * RS + FW];
-                        const double fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
-                        const double fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
-                        const double adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
-                        const double vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
-                                                 + 2.0 * ((w3 - wc) - (wc - w1)) * P.rdz2);
-                        g = ((r == 0) && bot) ? 0.0 : (vis - adv);
+                        const real ut_w = symz(a0, a1, a2, a3, f4);
+                        const real ut_e = symz(e0, e1, e2, e3, f4);
+                        const real wm3 = cm3[r * RS + FW], wm2 = cm2[r * RS + FW], wm1 = cm1[r * RS + FW];
+                        const real wp1 = cp1[r * RS + FW], wp2 = cp2[r * RS + FW], wp3 = cp3[r * RS + FW];
+                        const real fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
+                        const real fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
+                        const real adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
+                        const real vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
+                                                 + real(2) * ((w3 - wc) - (wc - w1)) * rdz2);
+                        g = ((r == 0) && bot) ? real(0) : (vis - adv);
                     }
-                    if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = g;
+                    if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = (double)g;
     #if RBC_EXPERIMENT_NOG0
                     wn[r] = wc + dt * (gam * g);
     #else
@@ -954,7 +1031,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         STAMP(4);
         lds_barrier();   // every read of the old state is done
         {
-            double *me = lds + k0 * RS + i;
+            real *me = lds + k0 * RS + i;
 #pragma unroll
             for (int r = 0; r < CZ; ++r) un[r] = me[r * RS + FB];          // U*_u comes back from its parking slot
 #pragma unroll
@@ -963,12 +1040,12 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
 #if RBC_EXPERIMENT_NOPROJECT
         lds_barrier();          // timing experiment only (WRONG numerics): what the stage costs without the Poisson solve
 #else
-        project<NX, NZ>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last, un, wn);
+        project<NX, NZ, T>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last, un, wn);
 #endif
         STAMP(12);
         if (st + 1 < nstage) {
             lds_barrier();   // phi reads done -> the b slot takes the new b
-            double *me = lds + k0 * RS + i;
+            real *me = lds + k0 * RS + i;
 #pragma unroll
             for (int r = 0; r < CZ; ++r) me[r * RS + FB] = bn[r];
             lds_barrier();
@@ -979,19 +1056,19 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     // =========================== outputs ========================================================
     // here: LDS u,w = final velocities (own cells), b slot = phi of the last stage, bn = final b
     __syncthreads();
-    double un[CZ], wn[CZ];
+    real un[CZ], wn[CZ];
     {
-        const double *me = lds + k0 * RS + i;
+        const real *me = lds + k0 * RS + i;
 #pragma unroll
         for (int r = 0; r < CZ; ++r) { un[r] = me[r * RS + FU]; wn[r] = me[r * RS + FW]; }
     }
-    // state back to HBM
+    // state back to HBM (always float64: the layout of the reference's checkpoint datasets)
 #pragma unroll
     for (int r = 0; r < CZ; ++r) {
         const int k = k0 + r;
-        gb_[k * NX + i] = bn[r];
-        gu_[k * NX + i] = un[r];
-        gw_[k * NX + i] = wn[r];
+        gb_[k * NX + i] = (double)bn[r];
+        gu_[k * NX + i] = (double)un[r];
+        gw_[k * NX + i] = (double)wn[r];
     }
     if (top) gw_[NZ * NX + i] = 0.0;
 
@@ -1003,33 +1080,33 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
     if (tid == 0) P.flags[env] = (bad > 0.0) ? 1 : 0;
 
     // pNHS = phi - mean(phi)   (the reference solver zeroes the mean mode)
-    double ph[CZ];
+    real ph[CZ];
     double psum = 0.0;
 #pragma unroll
-    for (int r = 0; r < CZ; ++r) { ph[r] = lds[(k0 + r) * RS + FB + i]; psum += ph[r]; }
+    for (int r = 0; r < CZ; ++r) { ph[r] = lds[(k0 + r) * RS + FB + i]; psum += (double)ph[r]; }
     psum = block_sum<G::NT>(psum, scr, tid);
-    const double pmean = psum / (double)G::NCELL;
+    const real pmean = (real)(psum / (double)G::NCELL);
 #pragma unroll
     for (int r = 0; r < CZ; ++r) ph[r] -= pmean;
 
     // pHY' (absolute) by the same column scan; the b slot (free now) takes the final b
-    double phy[CZ];
+    real phy[CZ];
     {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < CZ; ++r) lds[(k0 + r) * RS + FB + i] = bn[r];
         __syncthreads();
-        const double babove = top ? (bn[CZ - 1] + ((P.min_b - bn[CZ - 1]) * rhz) * dz) : lds[(k0 + CZ) * RS + FB + i];
-        double acc = 0.0;
+        const real babove = top ? (bn[CZ - 1] + ((min_b - bn[CZ - 1]) * rhz) * dz) : lds[(k0 + CZ) * RS + FB + i];
+        real acc = real(0);
 #pragma unroll
         for (int r = CZ - 1; r >= 0; --r) {
-            const double bup = (r == CZ - 1) ? babove : bn[r + 1];
-            acc += 0.5 * (bn[r] + bup);
+            const real bup = (r == CZ - 1) ? babove : bn[r + 1];
+            acc += real(0.5) * (bn[r] + bup);
             phy[r] = acc;
         }
         scr[c * NX + i] = acc;
         __syncthreads();
-        double above = 0.0;
+        real above = real(0);
         for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
 #pragma unroll
         for (int r = 0; r < CZ; ++r) phy[r] = -(phy[r] + above) * dz;
@@ -1047,8 +1124,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
             const int k = k0 + r;
             if (xs && (k % stz) == 0) {
                 const size_t o = (size_t)(k / stz) * P.obs_nx + (i / stx);
-                ob[o] = obs_value(P, 0, bn[r]); ob[och + o] = obs_value(P, 1, un[r]); ob[2 * och + o] = obs_value(P, 2, wn[r]);
-                ob[3 * och + o] = obs_value(P, 3, phy[r]); ob[4 * och + o] = obs_value(P, 4, ph[r]);
+                ob[o] = obs_value(P, 0, (double)bn[r]); ob[och + o] = obs_value(P, 1, (double)un[r]); ob[2 * och + o] = obs_value(P, 2, (double)wn[r]);
+                ob[3 * och + o] = obs_value(P, 3, (double)phy[r]); ob[4 * och + o] = obs_value(P, 4, (double)ph[r]);
             }
         }
         if (P.write_state) {
@@ -1062,7 +1139,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         }
     }
 
-    // A12 Nusselt numbers (get_nusselt rbc_sim2D_api.jl:142-163, array_gradient rbc_sim2D.jl:206-220)
+    // A12 Nusselt numbers (get_nusselt rbc_sim2D_api.jl:142-163, array_gradient rbc_sim2D.jl:206-220); sums in float64
+    const double kapd = P.nu_kappa[2 * env + 1];
     for (int which = 0; which < 2; ++which) {   // 0: full state, 1: sensor grid
         const int stx = which ? NX / P.obs_nx : 1, stz = which ? NZ / P.obs_nz : 1;
         const int mx = NX / stx, mz = NZ / stz;
@@ -1070,36 +1148,36 @@ __global__ __launch_bounds__(NX *(NZ / CZ)) void rbc2d_kernel(const Params2D P)
         const bool xs = (i % stx) == 0;
 #pragma unroll
         for (int r = 0; r < CZ; ++r)
-            if (xs && ((k0 + r) % stz) == 0) q1 += bn[r] * wn[r];
+            if (xs && ((k0 + r) % stz) == 0) q1 += (double)bn[r] * (double)wn[r];
         q1 = block_sum<G::NT>(q1, scr, tid);
         // row means of T on the (sub)grid: thread t sums segment seg of row
         __syncthreads();
         {
-            const int row = tid / 12, seg = tid - 12 * row;   // NT = 12*NZ threads: NX/8 = 12 segments per row
+            const int row = tid / N2, seg = tid - N2 * row;   // NT = N2*NZ threads: NX/8 = N2 segments of 8 cells per row
             double s = 0.0;
             if ((row % stz) == 0)
-                for (int j = 0; j < 8; ++j) { const int x = 8 * seg + j; if ((x % stx) == 0) s += lds[row * RS + FB + x]; }
-            scr[tid] = s;
+                for (int j = 0; j < 8; ++j) { const int x = 8 * seg + j; if ((x % stx) == 0) s += (double)lds[row * RS + FB + x]; }
+            scr[tid] = (real)s;
         }
         __syncthreads();
         if (tid < NZ) {
             double s = 0.0;
-            for (int j = 0; j < 12; ++j) s += scr[tid * 12 + j];
-            scr[G::NT + 66 + tid] = s / (double)mx;
+            for (int j = 0; j < N2; ++j) s += (double)scr[tid * N2 + j];
+            scr[G::NT + 66 + tid] = (real)(s / (double)mx);
         }
         __syncthreads();
         if (tid == 0) {
-            const double *tx = scr + G::NT + 66;
+            const real *tx = scr + G::NT + 66;
             double g = 0.0;
             for (int kk = 0; kk < mz; ++kk) {
-                const double cur = tx[kk * stz];
-                if (kk == 0) g += tx[stz] - cur;
-                else if (kk == mz - 1) g += cur - tx[(kk - 1) * stz];
-                else g += (tx[(kk + 1) * stz] - tx[(kk - 1) * stz]) / 2;
+                const double cur = (double)tx[kk * stz];
+                if (kk == 0) g += (double)tx[stz] - cur;
+                else if (kk == mz - 1) g += cur - (double)tx[(kk - 1) * stz];
+                else g += ((double)tx[(kk + 1) * stz] - (double)tx[(kk - 1) * stz]) / 2;
             }
-            const double q2 = kap * (g / mz);
+            const double q2 = kapd * (g / mz);
             const double q1m = q1 / ((double)mx * mz);
-            P.nusselt[(size_t)env * 2 + which] = (q1m - q2) / (kap * P.delta_b / P.lz);
+            P.nusselt[(size_t)env * 2 + which] = (q1m - q2) / (kapd * P.delta_b / P.lz);
         }
         __syncthreads();
     }

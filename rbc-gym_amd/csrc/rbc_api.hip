@@ -73,12 +73,30 @@ struct rbc_handle {
 
 namespace {
 
-template <int NX, int NZ>
+template <int NX, int NZ, typename T>
 void bind_kernel(rbc_handle *h)
 {
-    h->kernel = rbc::rbc2d_kernel<NX, NZ>;
-    h->lds_bytes = rbc::Geo<NX, NZ>::LDS_BYTES;
-    h->threads = rbc::Geo<NX, NZ>::NT;
+    h->kernel = rbc::rbc2d_kernel<NX, NZ, T>;
+    h->lds_bytes = rbc::Geo<NX, NZ, T>::LDS_BYTES;
+    h->threads = rbc::Geo<NX, NZ, T>::NT;
+}
+
+// The LDS-resident 2D kernel is instantiated for these grids (x periodic, lanes along x: NX = 8 * {8, 12, 16, 24}; NZ a
+// multiple of 16; NX * NZ <= 8192 threads-times-8; three fields of NX * NZ reals + scratch within the CU's 160 KiB).
+// float64 is the reference's arithmetic; float32 (RBC_PRECISION_F32) halves the footprint, so two workgroups share a CU
+// and the larger grids fit.
+bool bind_grid(rbc_handle *h, int nx, int nz, int precision)
+{
+#define RBC_GRID(NX_, NZ_, T_) if (nx == NX_ && nz == NZ_) { bind_kernel<NX_, NZ_, T_>(h); return true; }
+    if (precision == RBC_PRECISION_F64) {
+        RBC_GRID(96, 64, double) RBC_GRID(96, 48, double) RBC_GRID(96, 32, double)
+        RBC_GRID(64, 64, double) RBC_GRID(64, 48, double) RBC_GRID(64, 32, double)
+        RBC_GRID(128, 32, double)
+    } else if (precision == RBC_PRECISION_F32) {
+        RBC_GRID(96, 64, float) RBC_GRID(128, 64, float) RBC_GRID(64, 64, float) RBC_GRID(192, 32, float)
+    }
+#undef RBC_GRID
+    return false;
 }
 
 // Pivots of the z-direction operator of every Fourier mode (pressure solve):
@@ -182,7 +200,7 @@ int rbc_device_count(void)
 
 int rbc_has_precision(int precision)
 {
-    return precision == RBC_PRECISION_F64 ? 1 : 0;
+    return (precision == RBC_PRECISION_F64 || precision == RBC_PRECISION_F32) ? 1 : 0;
 }
 
 void rbc_default_config(rbc_config *c)
@@ -210,7 +228,7 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     if (cfg->abi_version != RBC_ABI_VERSION) return fail(RBC_ERR_INVALID, "rbc_config.abi_version mismatch");
     if (cfg->dim != 2 && cfg->dim != 3) return fail(RBC_ERR_INVALID, "dim must be 2 or 3");
     if (cfg->batch < 1) return fail(RBC_ERR_INVALID, "batch must be >= 1");
-    if (!rbc_has_precision(cfg->precision)) return fail(RBC_ERR_INVALID, "precision: this build carries RBC_PRECISION_F64 kernels only");
+    if (!rbc_has_precision(cfg->precision)) return fail(RBC_ERR_INVALID, "precision must be RBC_PRECISION_F64 or RBC_PRECISION_F32");
     if (cfg->dim == 3 && cfg->precision != RBC_PRECISION_F64) return fail(RBC_ERR_INVALID, "precision: the 3D path is float64 only");
     if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
     if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
@@ -228,12 +246,10 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     { const char *e = std::getenv("RBC_NO_TILE"); h->no_tile = e && e[0] == '1'; }
     { const char *e = std::getenv("RBC_NO_PAIR"); h->no_pair = e && e[0] == '1'; }
     if (cfg->dim == 3) { /* streaming kernels, any grid whose horizontal slab fits the LDS FFT */ }
-    else if (cfg->nx == 96 && cfg->nz == 64) bind_kernel<96, 64>(h);
-    else if (cfg->nx == 96 && cfg->nz == 48) bind_kernel<96, 48>(h);
-    else if (cfg->nx == 96 && cfg->nz == 32) bind_kernel<96, 32>(h);
-    else {
+    else if (!bind_grid(h, cfg->nx, cfg->nz, cfg->precision)) {
         delete h;
-        return fail(RBC_ERR_INVALID, "unsupported grid: the LDS-resident 2D kernel is built for nx=96, nz in {32,48,64}");
+        return fail(RBC_ERR_INVALID, "unsupported 2D grid: the LDS-resident kernel is built for (nx, nz) in float64: (96,64) (96,48) (96,32) "
+                                     "(64,64) (64,48) (64,32) (128,32); float32: (96,64) (128,64) (64,64) (192,32)");
     }
     h->ncell = (size_t)h->nx * h->nz * (cfg->dim == 3 ? cfg->ny : 1);
     h->env_stride = (size_t)(3 * h->nz + 1) * h->nx;
@@ -753,8 +769,8 @@ int rbc_copy_ceiling(int device, size_t bytes, int iters, double *kernel_gbs, do
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h)
 {
     if (!h) return 0.0;
-    // B_sub = 10 * F * C * s (F prognostic fields: 3 in 2D, 4 in 3D; C cells; s=8 bytes) per RK3 substep
-    return (double)h->nsub * 10.0 * (h->s3 ? 4.0 : 3.0) * (double)h->ncell * 8.0;
+    // B_sub = 10 * F * C * s (F prognostic fields: 3 in 2D, 4 in 3D; C cells; s = 8 bytes, 4 for the float32 variant) per RK3 substep
+    return (double)h->nsub * 10.0 * (h->s3 ? 4.0 : 3.0) * (double)h->ncell * (h->cfg.precision == RBC_PRECISION_F32 ? 4.0 : 8.0);
 }
 
 int rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, double *gv, double *gw, double *gb)

@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ID = "rbc_gym/RayleighBenardConvection2D-v0"
+ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
 
 
 @pytest.fixture(scope="module")

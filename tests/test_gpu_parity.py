@@ -2,6 +2,8 @@
 oracle on identical inputs.  All arithmetic is fp64; tolerances are stated per test.
 north_star tolerance: fields within 1e-6 rel-L2 of the reference solver; the HIP path is held
 to a far tighter bar against the oracle (round-off level) because both restate one algorithm."""
+import os
+
 import numpy as np
 import pytest
 
@@ -242,9 +244,15 @@ def test_masked_reset_and_nan_flag(native, ckpt_ra1e4):
     dict(nz=64, heaters=1, heater_limit=0.75, obs=(2, 1), dt_solver=0.03, dt_control=0.09, ra=1e4),
     dict(nz=64, heaters=10, heater_limit=0.75, obs=(8, 48), dt_solver=0.03, dt_control=0.09, ra=1e4),   # segment edges fall inside cells: cubic blends
     dict(nz=32, heaters=7, heater_limit=0.6, obs=(8, 48), dt_solver=0.03, dt_control=0.06, ra=1e4),
-], ids=["96x48", "96x32", "96x64-32heaters", "96x64-1heater", "96x64-10heaters-blends", "96x32-7heaters-blends"])
+    dict(nx=64, nz=64, heaters=8, heater_limit=0.75, obs=(8, 32), dt_solver=0.03, dt_control=0.09, ra=1e4),
+    dict(nx=64, nz=48, heaters=12, heater_limit=0.75, obs=(6, 16), dt_solver=0.03, dt_control=0.07, ra=2e4),        # blends: 64 cells / 12 segments
+    dict(nx=64, nz=32, heaters=4, heater_limit=0.5, obs=(4, 64), dt_solver=0.03, dt_control=0.09, ra=5e3, lx=4.0),
+    dict(nx=128, nz=32, heaters=12, heater_limit=0.75, obs=(8, 64), dt_solver=0.02, dt_control=0.07, ra=1e4),       # the reference's 12 heaters with ACTIVE blend zones (Nx >= 128, rbc_sim2D.jl:120-126)
+    dict(nx=128, nz=32, heaters=5, heater_limit=0.9, obs=(2, 32), dt_solver=0.02, dt_control=0.05, ra=3e4, lz=1.0),
+], ids=["96x48", "96x32", "96x64-32heaters", "96x64-1heater", "96x64-10heaters-blends", "96x32-7heaters-blends",
+        "64x64", "64x48-12heaters-blends", "64x32", "128x32-12heaters-blends", "128x32-5heaters"])
 def test_non_default_configurations_match_oracle(native, oracle, cfg):
-    """Every compiled grid (96x64, 96x48, 96x32) and the run-time parameters of initialize_simulation
+    """Every compiled float64 grid (NX in {64, 96, 128}: the x transform is 8 x {8, 12, 16}) and the run-time parameters of initialize_simulation
     (rbc_sim2D_api.jl:17-70: Ra, Pr, domain, plate temperatures, heaters, heater_limit, sensor grid, solver / control
     steps incl. a clipped last substep) away from the registry defaults: random reset, two actuated control intervals."""
     cfg = dict(cfg)
@@ -278,3 +286,106 @@ def test_non_default_configurations_match_oracle(native, oracle, cfg):
             assert np.allclose(ob[e][:4], o.obs_f32(5)[:4], rtol=1e-5, atol=1e-5)
     t, s = sim.get_info()
     assert np.allclose(t, 2 * cfg["dt_control"]) and np.all(s == 3)
+
+
+def test_heater_profile_with_active_blend_zones_matches_oracle(native, oracle):
+    """At the default 12 heaters the cubic blends of collate_actions_colin (rbc_sim2D.jl:120-126) only touch cell centres for
+    Nx >= 128: on the 128x32 grid the bottom-plate profile the kernel applies must be the oracle's (which restates the Julia
+    function line by line, tests/test_oracle_golden.py::test_heater_profile), blend cells included.  Observed through the
+    tendency of b in the bottom row: G_b = kappa (ghost - 2 b1 + b2) / dz^2 - adv, ghost = 2 T_b - b1."""
+    kw = dict(nx=128, nz=32, heaters=12, dt_solver=0.02, dt_control=0.06)
+    sim = native.NativeSim(batch=1, obs_nz=8, obs_nx=64, **kw)
+    sim.reset(np.array([3], dtype=np.uint64))
+    b, u, w = sim.get_fields()
+    o = oracle.OracleSim(obs=(8, 64), **kw)
+    o.reset_from_arrays(b[0], u[0], w[0])
+    act = np.random.default_rng(0).uniform(-1, 1, (1, 12)).astype(np.float32)
+    o.set_action(act[0]); o.update_state()
+    tb = o.bottom_profile()
+    inside = np.abs(tb - np.round((tb - 2) / 1e-9) * 1e-9 - 2) >= 0                     # all cells; count the blended ones below
+    seg = 2 * np.pi / 12
+    xp = ((np.arange(128) + 0.5) * (2 * np.pi / 128)) % seg
+    blended = (xp < 0.03) | (xp >= seg - 0.03)
+    assert blended.sum() >= 8 and inside.all()                                             # blend zones are hit on this grid
+    g, go = sim.debug_tendencies(act), o.tendencies()
+    for f in "buw":
+        assert np.abs(g[f][0] - go[f]).max() < 1e-11 * max(np.abs(go[f]).max(), 1.0), f
+    assert np.abs(g["b"][0][0][blended] - go["b"][0][blended]).max() < 1e-11 * np.abs(go["b"][0]).max()
+
+
+def test_unsupported_grids_fail_loudly(native):
+    for nx, nz in ((100, 64), (96, 40), (256, 64), (128, 64)):          # 128x64 float64 does not fit a CU's LDS (float32 does)
+        with pytest.raises(native.RbcError):
+            native.NativeSim(batch=1, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8)
+
+
+# ---------------------------------------------------------------------------------------------
+# float32 variant (rbc_config.precision = RBC_PRECISION_F32; SURVEY.md 8(b)/8(d) C2).  The reference computes in Float64;
+# this variant keeps float32 state and arithmetic in the kernel (I/O types unchanged).  Stated tolerances, against the
+# float64 oracle on identical initial conditions:
+#   one control interval (50 substeps) from a stored Ra=1e4 steady state: rel-L2 < 2e-5 (fields), 1e-4 (Nusselt)
+#   from the chaotic Ra=1e5 state: rel-L2 < 5e-4 (round-off amplified by the flow)
+#   discrete divergence after a step: < 3e-5 (float32 round-off of O(1) velocities over dx = 0.065; float64: 2e-13)
+# ---------------------------------------------------------------------------------------------
+def test_float32_variant_matches_the_float64_oracle_within_the_stated_tolerance(native, oracle, ckpt_ra1e4, ckpt_ra1e5):
+    assert native.has_precision("f32") and native.has_precision("f64")
+    ics = _ics(ckpt_ra1e4, ckpt_ra1e5)
+    sim = _start(native, ics, precision=1)
+    b, u, w = sim.get_fields()
+    for e, ic in enumerate(ics):                        # reset: float32 rounding of the stored state + projection
+        assert rel_l2(b[e], ic[1]) < 1e-7 and rel_l2(u[e], ic[2]) < 3e-6 and rel_l2(w[e], ic[3]) < 3e-6
+    act = _actions(len(ics), 21)
+    assert sim.step(act)
+    b, u, w = sim.get_fields()
+    nus, nuo = sim.get_nusselt()
+    obs = sim.get_obs(5)
+    dx, dz = 2 * np.pi / 96, 2 / 64
+    div = (np.roll(u, -1, 2) - u) / dx + (w[:, 1:] - w[:, :-1]) / dz
+    assert np.abs(div).max() < 3e-5, np.abs(div).max()
+    assert np.all(w[:, 0] == 0) and np.all(w[:, -1] == 0)
+    for e, (ra, b0, u0, w0) in enumerate(ics):
+        o = oracle.OracleSim(ra=ra)
+        o.reset_from_arrays(b0, u0, w0)
+        assert o.step(act[e])
+        ob, ou, ow = o.fields()
+        tol = 2e-5 if ra == 1e4 else 5e-4
+        assert rel_l2(b[e], ob) < tol and rel_l2(u[e], ou) < 10 * tol and rel_l2(w[e], ow) < 10 * tol, (ra, rel_l2(b[e], ob), rel_l2(u[e], ou), rel_l2(w[e], ow))
+        assert abs(nus[e] - o.nusselt(True)) < 20 * tol * abs(o.nusselt(True)) and abs(nuo[e] - o.nusselt(False)) < 20 * tol * abs(o.nusselt(False))
+        assert np.allclose(obs[e][:3], o.obs_f32(5)[:3], rtol=0, atol=200 * tol)
+    # same kernel, other grids that only exist in float32
+    for nx, nz in ((128, 64), (192, 32), (64, 64)):
+        s32 = native.NativeSim(batch=2, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8, precision=1, dt_control=0.09, random_kick=0.05)
+        s32.reset(np.array([5, 6], dtype=np.uint64))
+        a2 = _actions(2, 3)
+        assert s32.step(a2)
+        fb = s32.get_fields()
+        for e in range(2):
+            o = oracle.OracleSim(nx=nx, nz=nz, obs=(8, nx // 2), dt_control=0.09, kick=0.05)
+            o.reset_random(5 + e)
+            assert o.step(a2[e])
+            for x, y in zip(fb, o.fields()):
+                assert rel_l2(x[e], y) < 3e-5, (nx, nz, rel_l2(x[e], y))
+        s32.close()
+
+
+def test_float32_variant_lands_on_the_reference_attractor(native, golden_dir):
+    """the float32 variant run from rest at the reference's checkpoint protocol (kick 0.02, t = 600) settles on the same
+    steady state as the reference's 40 Float64 episodes: kinetic energy within 2e-5 relative (their own spread), Nusselt
+    numbers within 2e-4"""
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "oracle_ensemble_ra10000.json")))["reference"]
+    n = 128
+    sim = native.NativeSim(batch=n, random_kick=0.02, write_state=0, precision=1)
+    sim.reset(np.arange(n, dtype=np.uint64) + 4242)
+    zero = np.zeros((n, 12), np.float32)
+    for _ in range(400):
+        assert sim.step(zero)
+    b, u, w = sim.get_fields()
+    ke = 0.5 * ((u ** 2).mean((1, 2)) + (w[:, :64] ** 2).mean((1, 2)))
+    nus, nuo = sim.get_nusselt()
+    on = (np.abs(np.fft.rfft(w[:, 32], axis=1))[:, 1:].argmax(1) + 1) == 2
+    assert on.sum() > 0.8 * n
+    assert abs(ke[on].mean() - ref["ke_mean"]) < 2e-5 * ref["ke_mean"], (ke[on].mean(), ref["ke_mean"])
+    assert abs(nus[on].mean() - ref["nu_state_mean"]) < 2e-4 * ref["nu_state_mean"]
+    assert abs(nuo[on].mean() - ref["nu_obs_mean"]) < 2e-4 * ref["nu_obs_mean"]
+    sim.close()
