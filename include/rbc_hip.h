@@ -168,8 +168,8 @@ void *rbc_dev_fields(rbc_handle *h);   /* float64 [B][ b(nz*nx) | u(nz*nx) | w((
 int    rbc_set_profiling(rbc_handle *h, int max_launches);
 int    rbc_profile_read(rbc_handle *h, double *ms, int capacity);
 /* On-box streaming ceiling to report next to the 8 TB/s spec: copies `bytes` (rounded down to 16) from one
-   device buffer to another `iters` times after a warm-up, once with a 16-bytes-per-lane grid-stride copy kernel and once
-   with hipMemcpyAsync device-to-device; rates in GB/s count bytes read + bytes written.  Either output may be NULL.   */
+   device buffer to another `iters` times after a warm-up, with a 16-bytes-per-lane grid-stride copy kernel (best of five grid
+   sizes) and with hipMemcpyAsync device-to-device; rates in GB/s count bytes read + bytes written.  Either output may be NULL.   */
 int    rbc_copy_ceiling(int device, size_t bytes, int iters, double *kernel_gbs, double *memcpy_gbs);
 /* algorithmic HBM bytes of one env-step per env under SURVEY.md 8(d)'s convention          */
 double rbc_algorithmic_bytes_per_env_step(rbc_handle *h);

@@ -643,7 +643,7 @@ template <int NX, int NZ, typename T>
 __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) void rbc2d_kernel(const Params2D P)
 {
     using G = Geo<NX, NZ, T>;
-    typedef T real;                  // working precision: real (the reference's Float64) or float (the fp32 variant)
+    typedef T real;                  // working precision: double (the reference's Float64) or float (the fp32 variant)
     constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB, N2 = G::N2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_bytes_raw[];
     real *lds_raw = reinterpret_cast<real *>(lds_bytes_raw);
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     const int k0 = c * CZ;
     const bool top = (c == G::NC - 1);
 
-    const real dx = (real)P.dx, dz = (real)P.dz, rdx = (real)P.rdx, rdz = (real)P.rdz, rdx2 = (real)rdx2, rdz2 = (real)rdz2;
+    const real dx = (real)P.dx, dz = (real)P.dz, rdx = (real)P.rdx, rdz = (real)P.rdz, rdx2 = (real)P.rdx2, rdz2 = (real)P.rdz2;
     const real min_b = (real)P.min_b;
     const real nu = (real)P.nu_kappa[2 * env], kap = (real)P.nu_kappa[2 * env + 1];
 
@@ -1230,7 +1230,8 @@ __global__ __launch_bounds__(64) void cell_distance_kernel(const float *__restri
     for (int a = 0; a < P; ++a)
         for (int b = a + 1 + lane; b < P; b += 64) {
             const int i = min(peaks[a], peaks[b]), j = max(peaks[a], peaks[b]);
-            const double direct = fabs((double)j * step - (double)i * step), around = lx - direct;
+            // x_j - x_i with each product rounded on its own, as numpy does (no fma contraction: it would change the last bit)
+            const double direct = fabs(__dsub_rn(__dmul_rn((double)j, step), __dmul_rn((double)i, step))), around = __dsub_rn(lx, direct);
             double d = (around < direct) ? around : direct;
             if (direct < around) { if (cnt[j] - cnt[i] == 0) d = 0.0; }
             else if (cnt[nx] - cnt[j] == 0 && cnt[i] == 0) d = 0.0;

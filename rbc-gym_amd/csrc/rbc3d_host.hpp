@@ -13,6 +13,7 @@ struct rbc3_state {
     double2 *jct = nullptr;            // junction values of the packed z solve, [env][mode]
     double2 *spec = nullptr;
     size_t fft_lds = 0;
+    int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
     double tff = 1.0;
     // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" overrides them for the
     // "does the flowstats pin discriminate the time integrator" experiment; never set in production.
@@ -63,6 +64,7 @@ int create3d(rbc_handle *h)
     factor2(c.nx, s->plan.nx1, s->plan.nx2);
     factor2(c.ny, s->plan.ny1, s->plan.ny2);
     s->fft_lds = ((size_t)2 * c.nx * c.ny + c.nx + c.ny) * sizeof(double2);
+    { const int items = 8 * (c.nx > c.ny ? c.nx : c.ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
     const size_t B = h->B;
     for (int q = 0; q < 2; ++q) {
@@ -125,17 +127,17 @@ int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
     const int B = h->B;
     if (g.nz % 2 == 0 && !h->no_pair) {      // mirror slabs packed as one complex transform, z solve on the packed spectrum
         const dim3 gm_ = grid_for((size_t)B * g.nx * g.ny, 128);
-        hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
+        hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
         hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
         hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
-        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi, buf, dts, mask);
+        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi, buf, dts, mask);
         hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - g.nx * g.ny), 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
         HIP3(hipGetLastError());
         return RBC_OK;
     } else {
-        hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
+        hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
         hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, s->spec, s->tab, B);
-        hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(256), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
+        hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
     }
     hipLaunchKernelGGL(rbc3::k3_correct, grid_for((size_t)B * g.nc, 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
     HIP3(hipGetLastError());

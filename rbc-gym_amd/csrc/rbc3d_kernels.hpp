@@ -1097,13 +1097,27 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *ph
     double *sb = st + (size_t)env * g.env_stride;
     double *ulo = sb + g.nc + (size_t)k * pln, *uhi = sb + g.nc + (size_t)(nz - 1 - k) * pln;
     double *vlo = sb + 2 * (size_t)g.nc + (size_t)k * pln, *vhi = sb + 2 * (size_t)g.nc + (size_t)(nz - 1 - k) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) {
-        const int j = idx / nx, i = idx - j * nx;
-        const int w_ = j * nx + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nx + i;
-        const double2 c = A[idx], pw = A[w_], ps = A[s_];
-        // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
-        ulo[idx] -= (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] -= (c.y * sc - pw.y * sc) * g.rdx * dts;
-        vlo[idx] -= (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] -= (c.y * sc - ps.y * sc) * g.rdy * dts;
+    // all global loads of a batch first (the workgroup has only four waves to hide their latency), then the updates
+    constexpr int UB = 4;
+    for (int base = threadIdx.x; base < pln; base += UB * blockDim.x) {
+        double ul[UB], uh[UB], vl[UB], vh[UB];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+            const int idx = base + q * blockDim.x;
+            if (idx < pln) { ul[q] = ulo[idx]; uh[q] = uhi[idx]; vl[q] = vlo[idx]; vh[q] = vhi[idx]; }
+        }
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+            const int idx = base + q * blockDim.x;
+            if (idx < pln) {
+                const int j = idx / nx, i = idx - j * nx;
+                const int w_ = j * nx + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nx + i;
+                const double2 c = A[idx], pw = A[w_], ps = A[s_];
+                // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
+                ulo[idx] = ul[q] - (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] = uh[q] - (c.y * sc - pw.y * sc) * g.rdx * dts;
+                vlo[idx] = vl[q] - (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] = vh[q] - (c.y * sc - ps.y * sc) * g.rdy * dts;
+            }
+        }
     }
 }
 

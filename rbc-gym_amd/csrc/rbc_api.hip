@@ -740,14 +740,16 @@ int rbc_copy_ceiling(int device, size_t bytes, int iters, double *kernel_gbs, do
     if (rc == RBC_OK) bail(hipEventCreate(&e0), "hipEventCreate");
     if (rc == RBC_OK) bail(hipEventCreate(&e1), "hipEventCreate");
     if (rc == RBC_OK) bail(hipMemsetAsync(src, 1, n16 * 16, st), "hipMemsetAsync");
-    for (int which = 0; which < 2 && rc == RBC_OK; ++which) {
-        double *out = which ? memcpy_gbs : kernel_gbs;
-        if (!out) continue;
+    // which = 0: hipMemcpyAsync D2D; which >= 1: the copy kernel at several grid sizes (the best one is reported)
+    const int grids[] = {0, 256 * 4, 256 * 8, 256 * 16, 256 * 32, 256 * 64};
+    if (kernel_gbs) *kernel_gbs = 0.0;
+    for (int which = 0; which < 6 && rc == RBC_OK; ++which) {
+        if (which == 0 ? !memcpy_gbs : !kernel_gbs) continue;
         for (int it = -2; it < iters && rc == RBC_OK; ++it) {     // two warm-up rounds
             if (it == 0) bail(hipEventRecord(e0, st), "hipEventRecord");
-            if (which) bail(hipMemcpyAsync(dst, src, n16 * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+            if (which == 0) bail(hipMemcpyAsync(dst, src, n16 * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
             else {
-                hipLaunchKernelGGL(rbc::copy16_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
+                hipLaunchKernelGGL(rbc::copy16_kernel, dim3(grids[which]), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16);
                 bail(hipGetLastError(), "copy16_kernel");
             }
         }
@@ -755,7 +757,11 @@ int rbc_copy_ceiling(int device, size_t bytes, int iters, double *kernel_gbs, do
         if (rc == RBC_OK) bail(hipEventSynchronize(e1), "hipEventSynchronize");
         float ms = 0.0f;
         if (rc == RBC_OK) bail(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
-        if (rc == RBC_OK) *out = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+        if (rc == RBC_OK) {
+            const double gbs = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+            if (which == 0) *memcpy_gbs = gbs;
+            else if (gbs > *kernel_gbs) *kernel_gbs = gbs;
+        }
     }
     if (st) (void)hipStreamSynchronize(st);
     if (e0) (void)hipEventDestroy(e0);

@@ -27,6 +27,6 @@ if __name__ == "__main__":
     zm, zp, mods, big = spectral_z_scores(b[on], u[on], w[on], ref)
     print(f"library {os.environ.get('RBC_HIP_LIB', 'default')}: {int(on.sum())} of {n} members on the k=2 state")
     print(f"moduli: {zm.size} z-scores, max |z| {np.abs(zm).max():.2f}, rms {np.sqrt(np.mean(zm ** 2)):.2f}")
-    print(f"phases: {zp.size} cos/sin means, max |difference| {zp.max():.2e}")
+    print(f"phases: {zp.size} z-scores (strong modes), max |z| {np.abs(zp).max():.2f}, rms {np.sqrt(np.mean(zp ** 2)):.2f}")
     rel = np.abs(mods - ref["mod_mean"])[big] / ref["mod_mean"][big]
     print(f"relative difference of the mean moduli: max {rel.max():.2e}, median {np.median(rel):.2e}  (k = {SPEC_K})")

@@ -21,8 +21,8 @@ def field_spectra(b, u, w):
 def spectral_z_scores(b, u, w, ref, floor=1e-7):
     """z-scores of an ensemble of states (b, u: (m, nz, nx), w: (m, nz+1, nx), all on the k=2 steady state) against the
     reference's episode statistics `ref` (tests/golden/ckpt2d_ra10000_spectra.npz):
-    (z of the moduli whose reference mean exceeds `floor`, |difference| of the mean cos/sin of the cross phases where both
-    moduli do, mean moduli, mask of the moduli used)."""
+    (z of the moduli whose reference mean exceeds `floor`, z of the mean cos/sin of the cross phases of the strong modes,
+    mean moduli, mask of the moduli used)."""
     m = b.shape[0]
     mods, phs = zip(*[field_spectra(b[e], u[e], w[e, :-1]) for e in range(m)])
     mods, phs = np.array(mods), np.array(phs)
@@ -34,10 +34,14 @@ def spectral_z_scores(b, u, w, ref, floor=1e-7):
 
     zm = z(mods, ref["mod_mean"], ref["mod_std"])
     big = ref["mod_mean"] > floor
-    both = np.stack([big[0, 1:] & big[2, 1:], big[1, 1:] & big[2, 1:]])
-    # The steady rolls are mirror symmetric about their plume axes, which locks the cross phases to 0 / pi (b-w) and
-    # +-pi/2 (u-w): cos and sin are constants with a spread at round-off level, so they are compared in absolute terms
-    # (a z-score would divide round-off by round-off); the discriminating information is in the moduli.
-    dc = np.abs(np.cos(phs).mean(0) - ref["cos_mean"])[both]
-    ds = np.abs(np.sin(phs).mean(0) - ref["sin_mean"])[both]
-    return zm[big], np.concatenate([dc, ds]), mods.mean(0), big
+    strong = ref["mod_mean"] > 1e-4                    # phases of weak modes are dominated by the residual oscillation
+    both = np.stack([strong[0, 1:] & strong[2, 1:], strong[1, 1:] & strong[2, 1:]])
+    # Cross phases: where the rolls' mirror symmetry locks them (cos = +-1, sin = 0, or the reverse) the spread is round-off;
+    # where it does not, a state and its mirror image (x -> -x, another steady state) have opposite sin (b-w) or cos (u-w),
+    # and each ensemble holds both in binomial proportions -- so the standard error gets an absolute floor (1e-5, the
+    # relative spread of the moduli) and the comparison stays a z-score.
+    def zfloor(mine, mean, std):
+        sem = np.hypot(mine.std(0, ddof=1) / np.sqrt(m), std / np.sqrt(n_ref))
+        return (mine.mean(0) - mean) / np.maximum(sem, 1e-5)
+    zc, zs = zfloor(np.cos(phs), ref["cos_mean"], ref["cos_std"]), zfloor(np.sin(phs), ref["sin_mean"], ref["sin_std"])
+    return zm[big], np.concatenate([zc[both], zs[both]]), mods.mean(0), big

@@ -403,10 +403,10 @@ def test_from_rest_ensemble_lands_on_the_reference_attractor(golden_dir):
     # build with the other advecting-velocity rule (-DRBC_SYMLEVEL=1) misses it by far (scripts/spectral_pin.py).
     from spectral_invariants import spectral_z_scores
     spec_ref = np.load(os.path.join(golden_dir, "ckpt2d_ra10000_spectra.npz"))
-    zm, dphase, _, _ = spectral_z_scores(b[on], u[on], w[on], spec_ref)
-    assert zm.size > 500 and dphase.size > 300
+    zm, zphase, _, _ = spectral_z_scores(b[on], u[on], w[on], spec_ref)
+    assert zm.size > 500 and zphase.size > 100
     assert np.abs(zm).max() < 5.0 and np.sqrt(np.mean(zm ** 2)) < 1.6, (np.abs(zm).max(), np.sqrt(np.mean(zm ** 2)))   # recorded: 1.9 / 1.1; SYMLEVEL=1: 103 / 12
-    assert dphase.max() < 1e-3, dphase.max()                                # phases are symmetry-locked constants
+    assert np.abs(zphase).max() < 5.0, np.abs(zphase).max()                  # cross phases of the strong modes
 
 
 def test_ra_sweep_ensembles_match_the_reference_episode_statistics():
