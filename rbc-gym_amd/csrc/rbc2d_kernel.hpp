@@ -1230,8 +1230,11 @@ __global__ __launch_bounds__(64) void cell_distance_kernel(const float *__restri
     for (int a = 0; a < P; ++a)
         for (int b = a + 1 + lane; b < P; b += 64) {
             const int i = min(peaks[a], peaks[b]), j = max(peaks[a], peaks[b]);
-            // x_j - x_i with each product rounded on its own, as numpy does (no fma contraction: it would change the last bit)
-            const double direct = fabs(__dsub_rn(__dmul_rn((double)j, step), __dmul_rn((double)i, step))), around = __dsub_rn(lx, direct);
+            // x_j - x_i with each product rounded on its own, as numpy does: an fma contraction would change the last bit
+            // (HIP's __dmul_rn is a plain multiply that hipcc may still contract, hence the opaque values)
+            double xj = (double)j * step, xi = (double)i * step;
+            asm volatile("" : "+v"(xj), "+v"(xi));
+            const double direct = fabs(xj - xi), around = lx - direct;
             double d = (around < direct) ? around : direct;
             if (direct < around) { if (cnt[j] - cnt[i] == 0) d = 0.0; }
             else if (cnt[nx] - cnt[j] == 0 && cnt[i] == 0) d = 0.0;

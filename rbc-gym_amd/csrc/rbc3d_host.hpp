@@ -128,8 +128,12 @@ int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
     if (g.nz % 2 == 0 && !h->no_pair) {      // mirror slabs packed as one complex transform, z solve on the packed spectrum
         const dim3 gm_ = grid_for((size_t)B * g.nx * g.ny, 128);
         hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
-        hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
-        hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
+        if (g.nz == 32 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<16>, gm_, dim3(128), 0, h->stream, g, s->spec, s->tab, B);
+        else if (g.nz == 16 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<8>, gm_, dim3(128), 0, h->stream, g, s->spec, s->tab, B);
+        else {
+            hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
+            hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
+        }
         hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi, buf, dts, mask);
         hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - g.nx * g.ny), 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
         HIP3(hipGetLastError());

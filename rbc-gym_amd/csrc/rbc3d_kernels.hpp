@@ -1074,6 +1074,54 @@ __global__ void k3_thomas_pair_bwd(Geo3 g, double2 *spec, const double2 *jct, co
     }
 }
 
+// Both sweeps in one launch, the packed spectrum read and written ONCE: a thread owns a mode (kx, ky) together with its
+// conjugate partner (-kx, -ky) -- the only other mode its junction needs -- and keeps the forward results of both columns
+// (2 x HALF complex values) in registers between the sweeps.  Threads of the partner modes exit at once (whole waves, except
+// in the two self-conjugate rows).  Same recurrences in the same order as k3_thomas_pair_fwd / _bwd: bitwise the same result.
+template <int HALF>
+__global__ void __launch_bounds__(128) k3_thomas_pair_fused(Geo3 g, double2 *spec, const double *tab, int B)
+{
+    const int nx = g.nx, ny = g.ny, pln = nx * ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pln * B) return;
+    const int env = t / pln, mn = t - env * pln;
+    const int n = mn / nx, m = mn - n * nx;
+    const int mp = ((n == 0) ? 0 : ny - n) * nx + ((m == 0) ? 0 : nx - m);     // mode (-kx, -ky)
+    if (mp < mn) return;                                                       // the partner's thread does this pair
+    const bool self = (mp == mn);
+    double2 *sa = spec + (size_t)env * HALF * pln + mn, *sb = spec + (size_t)env * HALF * pln + mp;
+    const double o = g.rdz * g.rdz;
+    double2 ya[HALF], yb[HALF];
+    double inv[HALF];
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) { inv[k] = tab[(size_t)k * pln + mn]; ya[k] = sa[(size_t)k * pln]; yb[k] = sb[(size_t)k * pln]; }
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) {                                           // forward elimination (pivots depend on |kx|, |ky| only)
+        ar = ya[k].x * inv[k] - (inv[k] * o) * ar; ai = ya[k].y * inv[k] - (inv[k] * o) * ai;
+        br = yb[k].x * inv[k] - (inv[k] * o) * br; bi = yb[k].y * inv[k] - (inv[k] * o) * bi;
+        ya[k] = make_double2(ar, ai); yb[k] = make_double2(br, bi);
+    }
+    const double c = inv[HALF - 1] * o;
+    double xar, xai, xbr, xbi;
+    if (mn == 0) { xar = ar; xai = 0.0; xbr = ar; xbi = 0.0; }                  // singular mean mode: pin phi = 0 in slab nz/2
+    else {
+        const double jf = 1.0 / (1.0 - c * c);
+        xar = jf * (ar - c * bi); xai = jf * (ai - c * br);                    // X = jf (P - i c conj(P'))
+        xbr = jf * (br - c * ai); xbi = jf * (bi - c * ar);
+    }
+    sa[(size_t)(HALF - 1) * pln] = make_double2(xar, xai);
+    if (!self) sb[(size_t)(HALF - 1) * pln] = make_double2(xbr, xbi);
+#pragma unroll
+    for (int k = HALF - 2; k >= 0; --k) {                                      // back-substitution outward
+        const double cp = inv[k] * o;
+        xar = ya[k].x - cp * xar; xai = ya[k].y - cp * xai;
+        xbr = yb[k].x - cp * xbr; xbi = yb[k].y - cp * xbi;
+        sa[(size_t)k * pln] = make_double2(xar, xai);
+        if (!self) sb[(size_t)k * pln] = make_double2(xbr, xbi);
+    }
+}
+
 // inverse 2D FFT of a packed slab pair -> phi of slab k (real part) and of slab nz-1-k (imaginary part), and, with both
 // potentials of the slab still in LDS, the horizontal half of pressure_correct_velocities!: u -= dts dphi/dx, v -= dts dphi/dy
 // on the two slabs (st != nullptr).  The vertical half needs phi of the slab below: k3_correct_w.

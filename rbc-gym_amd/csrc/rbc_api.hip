@@ -45,6 +45,7 @@ struct rbc_handle {
     bool no_pair = false;              // RBC_NO_PAIR=1: unpacked 3D Poisson path (one FFT per slab; A/B and odd nz)
     bool no_tile = false;              // RBC_NO_TILE=1: skip the LDS-tiled 3D tendency kernels (A/B and debug)
     bool no_march = false;             // RBC_NO_MARCH=1: use the cell-per-thread 3D tendency kernels (A/B and debug)
+    bool no_fuse_z = false;            // RBC_NO_FUSE_Z=1: two-kernel z sweeps (A/B reference of k3_thomas_pair_fused)
     bool no_graph = true;              // RBC_USE_GRAPH=1 replays the 3D env-step as a captured HIP graph (measured: +1 %, so off by default)
     int B = 0, nx = 0, nz = 0;
     size_t ncell = 0, env_stride = 0, obs_sz = 0;
@@ -245,6 +246,7 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     { const char *e = std::getenv("RBC_NO_MARCH"); h->no_march = e && e[0] == '1'; }
     { const char *e = std::getenv("RBC_NO_TILE"); h->no_tile = e && e[0] == '1'; }
     { const char *e = std::getenv("RBC_NO_PAIR"); h->no_pair = e && e[0] == '1'; }
+    { const char *e = std::getenv("RBC_NO_FUSE_Z"); h->no_fuse_z = e && e[0] == '1'; }
     if (cfg->dim == 3) { /* streaming kernels, any grid whose horizontal slab fits the LDS FFT */ }
     else if (!bind_grid(h, cfg->nx, cfg->nz, cfg->precision)) {
         delete h;

@@ -322,6 +322,14 @@ def test_marching_and_generic_tendency_kernels_agree(native, o3, monkeypatch, sh
         assert sim.step(np.concatenate([act, act]))
         outs.append(sim.get_fields())
         sim.close()
+    monkeypatch.setenv("RBC_NO_TILE", "0"); monkeypatch.setenv("RBC_NO_MARCH", "0"); monkeypatch.setenv("RBC_NO_PAIR", "0")
+    monkeypatch.setenv("RBC_NO_FUSE_Z", "1")              # two-launch z sweeps instead of the fused one (nz = 16 here: HALF = 8)
+    sim = native.NativeSim3D(batch=2, shape=shape, domain=DOMAIN, ra=5000.0, dt_control=0.03, dt_solver=0.01)
+    sim.reset_from_arrays(*[np.stack([x, x[::1]]) for x in ic])
+    assert sim.step(np.concatenate([act, act]))
+    outs.append(sim.get_fields())
+    sim.close()
+    monkeypatch.delenv("RBC_NO_FUSE_Z")
     for other in outs[1:]:
         for x, y in zip(outs[0], other):
             assert rel_l2(x, y) < 1e-12
