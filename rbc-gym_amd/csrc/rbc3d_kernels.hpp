@@ -510,15 +510,23 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
     auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
     auto own = [&](const double *f, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + col]; };
 
-    // stage level k0 (u, v) and k0+1 (w; level k0 itself is only needed for the chunk's bottom face, read below)
-    double pfu[NPF], pfv[NPF], pfw[NPF];
+    // stage level k0 (u, v) and k0+1 (w; level k0 itself is only needed for the chunk's bottom face, read below).  Every
+    // global load of the prologue is issued here, before the first barrier, so that the workgroup waits for memory once
+    // instead of once per barrier (a workgroup lives for four levels: an exposed round trip is a tenth of its life).
+    const size_t eb = (size_t)t.env * g.env_stride;
+    const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
+    double pfu[NPF], pfv[NPF], pfw[NPF], pfw1[NPF];
     tile_fetch(t, u + (size_t)t.k0 * pl, pfu); tile_fetch(t, v + (size_t)t.k0 * pl, pfv);
     tile_fetch(t, w + (size_t)t.k0 * pl, pfw);
-    tile_store(t, PW, pfw);                                       // w(k0) first: bottom-face terms of the chunk
-    __syncthreads();
+    tile_fetch(t, w + (size_t)min(t.k0 + 1, nz) * pl, pfw1);
     double winu[6], winv[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) { winu[q] = own(u, t.k0 - 3 + q); winv[q] = own(v, t.k0 - 3 + q); }
+    // per-level global operands of this thread travel one level ahead of their use, like the planes
+    double nu5 = own(u, t.k0 + 3), nv5 = own(v, t.k0 + 3);
+    double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = use_gm ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
+    tile_store(t, PW, pfw);                                       // w(k0) first: bottom-face terms of the chunk
+    __syncthreads();
     double fbu = 0.0, dwbu = 0.0, fdnu, fbv = 0.0, dwbv = 0.0, fdnv;
     if (t.k0 > 0) {
         const double wc = L(IW, 0, 0), wmx = L(IW, -1, 0), wmy = L(IW, 0, -1);
@@ -529,15 +537,9 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
     } else { fdnu = ghost_lo(winu[3], 0.0); fdnv = ghost_lo(winv[3], 0.0); }
     __syncthreads();
     tile_store(t, PU, pfu); tile_store(t, PV, pfv);
-    tile_fetch(t, w + (size_t)min(t.k0 + 1, nz) * pl, pfw);
-    tile_store(t, PW, pfw);
+    tile_store(t, PW, pfw1);
     __syncthreads();
 
-    const size_t eb = (size_t)t.env * g.env_stride;
-    // per-level global operands of this thread travel one level ahead of their use, like the planes
-    double nu5 = own(u, t.k0 + 3), nv5 = own(v, t.k0 + 3);
-    const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
-    double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = use_gm ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
         const bool more = (k + 1 < t.k0 + KT3);
 #pragma unroll
@@ -645,6 +647,9 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
     auto cen = [&](const double *f, int c, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + c]; };
     auto fac = [&](int kk) -> double { return w[(size_t)min(max(kk, 0), nz) * pl + col]; };
 
+    // every global load of the prologue before the first barrier (see k3_tile_uv)
+    const size_t eb = (size_t)t.env * g.env_stride;
+    const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
     double pfw[NPF], pfb[NPF];
     tile_fetch(t, w + (size_t)t.k0 * pl, pfw); tile_fetch(t, b + (size_t)t.k0 * pl, pfb);
     double winw[6], winb[6], au[6], eu[6], av[6], ev[6];
@@ -654,18 +659,16 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
         au[q] = cen(u, col, t.k0 - 4 + q); eu[q] = cen(u, colE, t.k0 - 4 + q);
         av[q] = cen(v, col, t.k0 - 4 + q); ev[q] = cen(v, colN, t.k0 - 4 + q);
     }
+    // per-level global operands of this thread travel one level ahead of their use, like the planes
+    double nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
+    double nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = cen(v, col, t.k0 + 2), nev = cen(v, colN, t.k0 + 2);
+    double ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0, ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : 0.0;
     double fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : 0.0;
     double fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : 0.0;
     double bdn = (t.k0 > 0) ? winb[2] : ghost_lo(winb[3], bottom_T(g, actT + (size_t)t.env * g.heaters * g.heaters, t.i, t.j));
     tile_store(t, PW, pfw); tile_store(t, PB, pfb);
     __syncthreads();
 
-    const size_t eb = (size_t)t.env * g.env_stride;
-    // per-level global operands of this thread travel one level ahead of their use, like the planes
-    double nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
-    double nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = cen(v, col, t.k0 + 2), nev = cen(v, colN, t.k0 + 2);
-    const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
-    double ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0, ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : 0.0;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
         const bool more = (k + 1 < t.k0 + KT3);
 #pragma unroll
