@@ -525,3 +525,35 @@ def test_device_side_cell_distances_are_bit_identical_to_the_numpy_wrapper(gym):
         seen.update(cd.tolist())
     assert len(seen) > 3                                    # convection has set in: several distinct cell distances occurred
     venv.close(); raw.close()
+
+
+def test_running_on_torchs_default_stream_orders_without_explicit_syncs(gym):
+    """rbc_set_stream(hipStreamLegacy) puts the sim ON the legacy default stream, which is PyTorch's default stream: actions
+    produced by torch kernels and observations consumed by torch kernels are then ordered by the stream itself.  (Handle 0
+    keeps meaning "the handle's own non-blocking stream", which needs explicit synchronisation.)"""
+    torch = pytest.importorskip("torch")
+    from rbc_gym import _native
+    n = 64
+    ref = _native.NativeSim(batch=n, dt_control=0.3)
+    sim = _native.NativeSim(batch=n, dt_control=0.3)
+    seeds = np.arange(n, dtype=np.uint64) + 9
+    ref.reset(seeds); sim.reset(seeds)
+    h = _native.torch_stream_handle(torch.cuda.current_stream())
+    assert h == 1                                                       # torch's default stream has handle 0 -> hipStreamLegacy
+    sim._check(sim.lib.rbc_set_stream(sim.h, h))
+    from rbc_gym.vector import DeviceArray
+    p = sim.dev_ptrs()
+    obs_view = torch.as_tensor(DeviceArray(p["obs"], (n, 5, 8, 48), "<f4", sim), device="cuda")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    big = torch.empty((4096, 4096), device="cuda")
+    outs = []
+    for step in range(3):
+        big.normal_(generator=gen)                                      # a long torch kernel in front of the action kernel
+        acts = (big[:n, :12].clamp(-1, 1)).contiguous()                 # produced on torch's stream, never synchronised
+        sim.step_dev(acts.data_ptr())
+        outs.append((acts.cpu().numpy(), obs_view.clone().cpu().numpy()))   # torch reads the view on the same stream
+    for a, o in outs:
+        assert ref.step(a)
+        assert np.array_equal(ref.get_obs(5), o)
+    sim._check(sim.lib.rbc_set_stream(sim.h, None))                     # back to the own stream
+    sim.close(); ref.close()
