@@ -90,6 +90,7 @@ struct Params2D {
     double lx, lz, min_b, delta_b, heater_limit, kick;
     double dx, dz, rdx, rdz, rdx2, rdz2, rhz;   // uniform grid metrics (host-computed so they stay scalar-loadable)
     double dt, dt_last;
+    int batch;                 // number of envs B (the packed variant pairs them up: the last workgroup of an odd batch runs one)
     int nsub;                  // number of RK3 substeps (the last one uses dt_last)
     int heaters;
     int mode;
@@ -299,6 +300,26 @@ template <int N2, typename T> __device__ __forceinline__ void dft_n2(T *re, T *i
 }
 
 // ------------------------------------------------------------------------------------------
+// Real types of the kernel.  double and float are one env per workgroup.  f32x2 is the PACKED float32 variant: every value
+// is a pair (env 2w, env 2w+1) of the workgroup's two envs and every arithmetic instruction is a v_pk_{add,mul,fma}_f32 that
+// advances both -- CDNA4 issues a packed-f32 instruction in the slot of one f64 instruction, so the pair runs through exactly
+// the f64 kernel's instruction stream (same LDS layout with 8-byte slots, same registers) at two envs per instruction.
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct LaneT { static constexpr int N = 1; typedef T S; };
+template <> struct LaneT<f32x2> { static constexpr int N = 2; typedef float S; };
+template <typename T> __device__ __forceinline__ T bc(double x) { return (T)x; }                  // a double constant in every lane
+template <> __device__ __forceinline__ f32x2 bc<f32x2>(double x) { return f32x2((float)x); }
+__device__ __forceinline__ double lane(double x, int) { return x; }
+__device__ __forceinline__ float lane(float x, int) { return x; }
+__device__ __forceinline__ float lane(f32x2 x, int e) { return e ? x.y : x.x; }
+__device__ __forceinline__ void set_lane(double &x, int, double v) { x = v; }
+__device__ __forceinline__ void set_lane(float &x, int, float v) { x = v; }
+__device__ __forceinline__ void set_lane(f32x2 &x, int e, float v) { if (e) x.y = v; else x.x = v; }
+// two consecutive reals as one aligned unit (16-byte accesses for 8-byte reals) of the G^- workspace
+template <typename T> struct alignas(2 * sizeof(T)) Two { T x, y; };
+
+// ------------------------------------------------------------------------------------------
 // LDS layout: rows interleave the three fields, F(k, f, i) = lds[(3k + f) * NX + i] with
 // f = 0:u 1:w 2:b (the b slot doubles as the Poisson right-hand side / potential).  One
 // address VGPR per stencil column then reaches every field and row through the 16-bit
@@ -415,7 +436,7 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
     T *tabB = lds + NZ * RS - TSPLIT * G::NH;               // indexed with the global row number
     T tstage[TPER];
 #pragma unroll
-    for (int q = 0; q < TPER; ++q) { const int idx = tid + q * G::NT; tstage[q] = (T)tri_inv[min(idx, TN - 1)]; }
+    for (int q = 0; q < TPER; ++q) { const int idx = tid + q * G::NT; tstage[q] = bc<T>(tri_inv[min(idx, TN - 1)]); }
     // rhs = div(U*)/dts   (solve_for_pressure!, [OC] solve_for_pressure.jl).  un/wn = this thread's own U* cells
     // (also in LDS for the neighbours); only the east u and the w face above the chunk are read.
     {
@@ -495,7 +516,7 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
     const bool sw_up = tid < NX, sw_dn = (tid >= NXP) && (tid < NXP + NX);
     const int tj = sw_up ? tid : tid - NXP;
     const int tm = min(tj, NX - tj);
-    const T cpf = rdz * rdz * (T)NX;                // cp_k = tab_k * cpf
+    const T cpf = rdz * rdz * bc<T>((double)NX);                // cp_k = tab_k * cpf
     const int tp = (tj == 0) ? 0 : NX - tj;                   // junction partner column (mode NX-m)
     T *colb = lds + FB + mode_pos<N2>(tj);
     T *jctA = tabA + TSPLIT * G::NH, *jctB = tabB + TROWS * G::NH;
@@ -652,8 +673,11 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     real *tw = Sc;                   // [N2][8][2] twiddles c,s of W_NX^(n2*k1) = c - i s
     real *scr = Sc + G::TW;          // reductions / column-scan partials (NT + 130 reals)
 
-    const int env = blockIdx.x;
-    if (P.mask && !P.mask[env]) return;
+    constexpr int NL = LaneT<T>::N;
+    typedef typename LaneT<T>::S scal;
+    if constexpr (NL == 1) {
+        if (P.mask && !P.mask[blockIdx.x]) return;
+    }
     const int tid = threadIdx.x;
     unsigned long long stamp_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = 0;
@@ -664,22 +688,25 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     const int k0 = c * CZ;
     const bool top = (c == G::NC - 1);
 
-    const real dx = (real)P.dx, dz = (real)P.dz, rdx = (real)P.rdx, rdz = (real)P.rdz, rdx2 = (real)P.rdx2, rdz2 = (real)P.rdz2;
-    const real min_b = (real)P.min_b;
-    const real nu = (real)P.nu_kappa[2 * env], kap = (real)P.nu_kappa[2 * env + 1];
-
+    const real dx = bc<real>(P.dx), dz = bc<real>(P.dz), rdx = bc<real>(P.rdx), rdz = bc<real>(P.rdz), rdx2 = bc<real>(P.rdx2), rdz2 = bc<real>(P.rdz2);
+    const real min_b = bc<real>(P.min_b);
+    real nu, kap, Tb;
+    real bn[CZ];
     if (tid < NX) {                  // N2 * 8 = NX twiddles
         const int n2 = tid / 8, k1 = tid - 8 * n2;
         double s, cc;
         sincospi(2.0 * (double)(n2 * k1) / (double)NX, &s, &cc);
-        tw[2 * tid] = (real)cc; tw[2 * tid + 1] = (real)s;
+        tw[2 * tid] = bc<real>(cc); tw[2 * tid + 1] = bc<real>(s);
     }
 
+    if constexpr (NL == 1) {
+    // one env per workgroup: the round-1 prologue verbatim (see the note at the outputs: the kernel sits at hipcc's scalar
+    // register limit and the shape of this code decides where the spills land)
+    const int env = blockIdx.x;
+    nu = (real)P.nu_kappa[2 * env]; kap = (real)P.nu_kappa[2 * env + 1];
     double *gf = P.fields + (size_t)env * G::ENV_STRIDE;
     double *gb_ = gf, *gu_ = gf + G::NCELL, *gw_ = gf + 2 * G::NCELL;
-
     // ---- A10: heater profile of this column (collate_actions_colin, rbc_sim2D.jl:87-133) ----
-    real Tb;
     {
         double Tbd;
         const int n = P.heaters;
@@ -707,7 +734,6 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     }
 
     // ---- load (or generate) the state of the own cells --------------------------------------
-    real bn[CZ];
     {
         real *me = lds + k0 * RS + i;
         if (P.mode == MODE_RANDOM) {   // initialize_model, rbc_sim2D.jl:163-171
@@ -734,6 +760,94 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
         for (int r = 0; r < CZ; ++r) bn[r] = me[r * RS + FB];
     }
 
+    } else {
+    // lanes: the env(s) of this workgroup.  A lane beyond the batch (odd batch, packed variant) or masked out of a reset
+    // computes along on a copy of lane 0's env and stores nothing.
+    const int wg = blockIdx.x;
+    int envs[NL];
+    bool live[NL];
+    bool any_live = false;
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+        const int id = wg * NL + e;
+        envs[e] = (id < P.batch) ? id : wg * NL;
+        live[e] = (id < P.batch) && !(P.mask && !P.mask[envs[e]]);
+        any_live = any_live || live[e];
+    }
+    if (!any_live) return;
+#pragma unroll
+    for (int e = 0; e < NL; ++e) { set_lane(nu, e, (scal)P.nu_kappa[2 * envs[e]]); set_lane(kap, e, (scal)P.nu_kappa[2 * envs[e] + 1]); }
+
+    double *gf[NL];
+#pragma unroll
+    for (int e = 0; e < NL; ++e) gf[e] = P.fields + (size_t)envs[e] * G::ENV_STRIDE;      // b | u | w of lane e
+
+    // ---- A10: heater profile of this column (collate_actions_colin, rbc_sim2D.jl:87-133) ----
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+        double Tbd;
+        const int n = P.heaters;
+        const double ampl = P.heater_limit, hdx = 0.03;
+        const bool zero_action = (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM || P.actions == nullptr);
+        const float *act = zero_action ? nullptr : P.actions + (size_t)envs[e] * n;
+        double mean = 0.0, dev = 0.0;
+        for (int a = 0; a < n; ++a) mean += ampl * (act ? (double)act[a] : 0.0);
+        mean /= n;
+        for (int a = 0; a < n; ++a) dev = fmax(dev, fabs(ampl * (act ? (double)act[a] : 0.0) - mean));
+        double K2 = dev / ampl;
+        if (!(K2 > 1.0)) K2 = 1.0;
+        const double seg = P.lx / n, x = (i + 0.5) * P.dx;
+        int xs = (int)floor(x / seg) + 1;
+        if (xs > n) xs = n;
+        const int a0 = (xs == 1) ? n : xs - 1, a2 = (xs == n) ? 1 : xs + 1;
+        const double T0 = 2 + (ampl * (act ? (double)act[a0 - 1] : 0.0) - mean) / K2;
+        const double T1 = 2 + (ampl * (act ? (double)act[xs - 1] : 0.0) - mean) / K2;
+        const double T2 = 2 + (ampl * (act ? (double)act[a2 - 1] : 0.0) - mean) / K2;
+        const double xp = x - (xs - 1) * seg;
+        if (xp < hdx) Tbd = T0 + ((T0 - T1) / (4 * hdx * hdx * hdx)) * (xp - 2 * hdx) * (xp + hdx) * (xp + hdx);
+        else if (xp >= seg - hdx) Tbd = T1 + ((T1 - T2) / (4 * hdx * hdx * hdx)) * (xp - seg - 2 * hdx) * (xp - seg + hdx) * (xp - seg + hdx);
+        else Tbd = T1;
+        set_lane(Tb, e, (scal)Tbd);
+    }
+
+    // ---- load (or generate) the state of the own cells --------------------------------------
+    {
+        real *me = lds + k0 * RS + i;
+        if (P.mode == MODE_RANDOM) {   // initialize_model, rbc_sim2D.jl:163-171
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                const uint32_t id = (uint32_t)(k * NX + i);
+                real vu, vw, vb;
+#pragma unroll
+                for (int e = 0; e < NL; ++e) {
+                    const uint64_t seed = P.seeds[envs[e]];
+                    set_lane(vu, e, (scal)(P.kick * normal_deviate(seed, 0, id)));
+                    set_lane(vw, e, (k == 0) ? (scal)0 : (scal)(P.kick * normal_deviate(seed, 1, id)));
+                    const double z = (k + 0.5) * P.dz;
+                    const double v = P.min_b + (P.lz - z) * P.delta_b / 2 + P.kick * normal_deviate(seed, 2, id);
+                    set_lane(vb, e, (scal)fmin(fmax(v, P.min_b), P.min_b + P.delta_b));
+                }
+                me[r * RS + FU] = vu; me[r * RS + FW] = vw; me[r * RS + FB] = vb;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                real vu, vw, vb;
+#pragma unroll
+                for (int e = 0; e < NL; ++e) {
+                    set_lane(vb, e, (scal)gf[e][k * NX + i]);
+                    set_lane(vu, e, (scal)gf[e][G::NCELL + k * NX + i]);
+                    set_lane(vw, e, (k == 0) ? (scal)0 : (scal)gf[e][2 * G::NCELL + k * NX + i]);
+                }
+                me[r * RS + FB] = vb; me[r * RS + FU] = vu; me[r * RS + FW] = vw;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) bn[r] = me[r * RS + FB];
+    }
+
+    }
     // G^- (previous stage tendencies).  Only G^-_u stays in registers across stages; G^-_b and
     // G^-_w are parked in an L2-resident global workspace ([field][tid][8]: four 16-byte accesses
     // per thread, a wave covers 4 KiB contiguously) and fetched back one pass ahead of their use, so
@@ -742,12 +856,12 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     real g0u[CZ];
 #pragma unroll
     for (int r = 0; r < CZ; ++r) g0u[r] = real(0);
-    typedef real dbl2 __attribute__((ext_vector_type(2)));
-    real *gpark = reinterpret_cast<real *>(P.gpark);       // the workspace holds the working precision
-    dbl2 *park_b = reinterpret_cast<dbl2 *>(gpark + (((size_t)env * 2 + 0) * G::NT + tid) * CZ);
-    dbl2 *park_w = reinterpret_cast<dbl2 *>(gpark + (((size_t)env * 2 + 1) * G::NT + tid) * CZ);
+    typedef Two<real> dbl2;
+    real *gpark = reinterpret_cast<real *>(P.gpark);       // the workspace holds the working precision, one slice per workgroup
+    dbl2 *park_b = reinterpret_cast<dbl2 *>(gpark + (((size_t)blockIdx.x * 2 + 0) * G::NT + tid) * CZ);
+    dbl2 *park_w = reinterpret_cast<dbl2 *>(gpark + (((size_t)blockIdx.x * 2 + 1) * G::NT + tid) * CZ);
 
-    const real rhz = (real)P.rhz;   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
+    const real rhz = bc<real>(P.rhz);   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
     const int nstage = (P.mode == MODE_STEP) ? 3 * P.nsub : ((P.mode == MODE_TENDENCY) ? 1 : 0);
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
@@ -771,13 +885,13 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     STAMP(0);
     for (int st = 0; st < nstage; ++st) {
         const int sub = st / 3, ph = st - 3 * sub;
-        const real dt = (real)((sub == P.nsub - 1) ? P.dt_last : P.dt);
+        const real dt = bc<real>((sub == P.nsub - 1) ? P.dt_last : P.dt);
         // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl)
         const real gam = (ph == 0) ? real(8.0 / 15.0) : (ph == 1 ? real(5.0 / 12.0) : real(3.0 / 4.0));
         const real zet = (ph == 0) ? real(0.0) : (ph == 1 ? real(-17.0 / 60.0) : real(-5.0 / 12.0));
         const real dts = (gam + zet) * dt;
         const bool dbg = (P.mode == MODE_TENDENCY);
-        double *dg = dbg ? P.dbg_g + (size_t)env * 3 * G::NCELL : nullptr;
+        double *dg = dbg ? P.dbg_g + (size_t)blockIdx.x * NL * 3 * G::NCELL : nullptr;   // operator-level hook: lane 0 (the packed variant is not bound to it)
         STAMP(14);
         // column addresses of the 7-point x stencil, shared by all fields and rows; re-derived every
         // stage (see opaque()) so they do not occupy registers through the Poisson phases
@@ -887,7 +1001,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
                     dbu = d;
                     const real dphy = -(pacc + above) * dz;
                     const real g = vis - adv - dphy * rdx;
-                    if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = (double)g;
+                    if (dbg) dg[G::NCELL + (k0 + r) * NX + i] = (double)lane(g, 0);
     #if RBC_EXPERIMENT_NOG0
                     un[r] = u0 + dt * (gam * g);
     #else
@@ -935,7 +1049,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
                     const real adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
                     const real dif = kap * (((bp1 - b0) - (b0 - bm1)) * rdx2 + ((bup - b0) - (b0 - bdn)) * rdz2);
                     const real g = dif - adv;
-                    if (dbg) dg[(k0 + r) * NX + i] = (double)g;
+                    if (dbg) dg[(k0 + r) * NX + i] = (double)lane(g, 0);
     #if RBC_EXPERIMENT_NOG0
                     bn[r] = b0 + dt * (gam * g);
     #else
@@ -1006,7 +1120,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
                                                  + real(2) * ((w3 - wc) - (wc - w1)) * rdz2);
                         g = ((r == 0) && bot) ? real(0) : (vis - adv);
                     }
-                    if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = (double)g;
+                    if (dbg) dg[2 * G::NCELL + (k0 + r) * NX + i] = (double)lane(g, 0);
     #if RBC_EXPERIMENT_NOG0
                     wn[r] = wc + dt * (gam * g);
     #else
@@ -1054,6 +1168,13 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     }
 
     // =========================== outputs ========================================================
+    if constexpr (LaneT<T>::N == 1) {
+    // one env per workgroup: this block is the round-1 code verbatim -- hipcc's scalar-register allocation for the whole
+    // kernel is at its limit (106 SGPRs, 60 spilled into VGPR lanes) and any change of shape here moves v_readlane
+    // instructions into the hot passes (measured: +6 % per launch with the lane-generic block below)
+    const int env = blockIdx.x;
+    double *gf1 = P.fields + (size_t)env * G::ENV_STRIDE;
+    double *gb_ = gf1, *gu_ = gf1 + G::NCELL, *gw_ = gf1 + 2 * G::NCELL;
     // here: LDS u,w = final velocities (own cells), b slot = phi of the last stage, bn = final b
     __syncthreads();
     real un[CZ], wn[CZ];
@@ -1186,6 +1307,158 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     if ((tid == 0 || tid == (int)blockDim.x - 1) && P.stamps)
         for (int j = 0; j < 24; ++j) P.stamps[(size_t)env * 64 + (tid ? 32 : 0) + j] = stamp_acc[j];
 #endif
+    } else {
+    // here: LDS u,w = final velocities (own cells), b slot = phi of the last stage, bn = final b
+    __syncthreads();
+    real un[CZ], wn[CZ];
+    {
+        const real *me = lds + k0 * RS + i;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) { un[r] = me[r * RS + FU]; wn[r] = me[r * RS + FW]; }
+    }
+    // phi of the last stage (b slot) before the slot takes the final b
+    real ph[CZ];
+#pragma unroll
+    for (int r = 0; r < CZ; ++r) ph[r] = lds[(k0 + r) * RS + FB + i];
+
+    // pHY' (absolute) by the same column scan; the b slot (free now) takes the final b
+    real phy[CZ];
+    {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) lds[(k0 + r) * RS + FB + i] = bn[r];
+        __syncthreads();
+        const real babove = top ? (bn[CZ - 1] + ((min_b - bn[CZ - 1]) * rhz) * dz) : lds[(k0 + CZ) * RS + FB + i];
+        real acc = real(0);
+#pragma unroll
+        for (int r = CZ - 1; r >= 0; --r) {
+            const real bup = (r == CZ - 1) ? babove : bn[r + 1];
+            acc += real(0.5) * (bn[r] + bup);
+            phy[r] = acc;
+        }
+        scr[c * NX + i] = acc;
+        __syncthreads();
+        real above = real(0);
+        for (int cc = G::NC - 1; cc > c; --cc) above += scr[cc * NX + i];
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) phy[r] = -(phy[r] + above) * dz;
+    }
+    // now LDS: u, w, b slots = final fields (of every lane)
+
+    scal *sscr = reinterpret_cast<scal *>(scr);          // reductions run per lane on scalars
+    // the lane -> env map is re-derived here from an opaque copy of the workgroup index: kept alive across the stage loop it
+    // costs scalar registers that hipcc then spills into VGPR lanes (v_readlane in the hot passes: +6 % on the f64 kernel)
+    int wg_o = blockIdx.x;
+    asm volatile("" : "+s"(wg_o));
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+        const int id = wg_o * NL + e;
+        if (id >= P.batch || (P.mask && !P.mask[id])) continue;      // uniform over the workgroup: this lane stores nothing
+        const int env = id;
+        // state back to HBM (always float64: the layout of the reference's checkpoint datasets)
+        {
+            double *gf_e = P.fields + (size_t)env * G::ENV_STRIDE;
+            double *gb_ = gf_e, *gu_ = gf_e + G::NCELL, *gw_ = gf_e + 2 * G::NCELL;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                gb_[k * NX + i] = (double)lane(bn[r], e);
+                gu_[k * NX + i] = (double)lane(un[r], e);
+                gw_[k * NX + i] = (double)lane(wn[r], e);
+            }
+            if (top) gw_[NZ * NX + i] = 0.0;
+        }
+
+        // A13 NaN flag
+        double bad = 0.0;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) bad += (isnan(lane(bn[r], e)) || isnan(lane(un[r], e)) || isnan(lane(wn[r], e))) ? 1.0 : 0.0;
+        bad = block_sum<G::NT>(bad, sscr, tid);
+        if (tid == 0) P.flags[env] = (bad > 0.0) ? 1 : 0;
+
+        // pNHS = phi - mean(phi)   (the reference solver zeroes the mean mode)
+        double psum = 0.0;
+#pragma unroll
+        for (int r = 0; r < CZ; ++r) psum += (double)lane(ph[r], e);
+        psum = block_sum<G::NT>(psum, sscr, tid);
+        const scal pmean = (scal)(psum / (double)G::NCELL);
+
+        // A11 observation / state (float32, channel order b,u,w,pHY',pNHS; layout [c][z][x])
+        {
+            const int stx = NX / P.obs_nx, stz = NZ / P.obs_nz;
+            float *ob = P.obs + (size_t)env * 5 * P.obs_nz * P.obs_nx;
+            const size_t och = (size_t)P.obs_nz * P.obs_nx;
+            const bool xs = (i % stx) == 0;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r) {
+                const int k = k0 + r;
+                if (xs && (k % stz) == 0) {
+                    const size_t o = (size_t)(k / stz) * P.obs_nx + (i / stx);
+                    ob[o] = obs_value(P, 0, (double)lane(bn[r], e)); ob[och + o] = obs_value(P, 1, (double)lane(un[r], e));
+                    ob[2 * och + o] = obs_value(P, 2, (double)lane(wn[r], e));
+                    ob[3 * och + o] = obs_value(P, 3, (double)lane(phy[r], e)); ob[4 * och + o] = obs_value(P, 4, (double)(lane(ph[r], e) - pmean));
+                }
+            }
+            if (P.write_state) {
+                float *sb = P.state32 + (size_t)env * 5 * G::NCELL;
+#pragma unroll
+                for (int r = 0; r < CZ; ++r) {
+                    const int o = (k0 + r) * NX + i;
+                    sb[o] = (float)lane(bn[r], e); sb[G::NCELL + o] = (float)lane(un[r], e); sb[2 * G::NCELL + o] = (float)lane(wn[r], e);
+                    sb[3 * G::NCELL + o] = (float)lane(phy[r], e); sb[4 * G::NCELL + o] = (float)(lane(ph[r], e) - pmean);
+                }
+            }
+        }
+
+        // A12 Nusselt numbers (get_nusselt rbc_sim2D_api.jl:142-163, array_gradient rbc_sim2D.jl:206-220); sums in float64
+        const double kapd = P.nu_kappa[2 * env + 1];
+        for (int which = 0; which < 2; ++which) {   // 0: full state, 1: sensor grid
+            const int stx = which ? NX / P.obs_nx : 1, stz = which ? NZ / P.obs_nz : 1;
+            const int mx = NX / stx, mz = NZ / stz;
+            double q1 = 0.0;
+            const bool xs = (i % stx) == 0;
+#pragma unroll
+            for (int r = 0; r < CZ; ++r)
+                if (xs && ((k0 + r) % stz) == 0) q1 += (double)lane(bn[r], e) * (double)lane(wn[r], e);
+            q1 = block_sum<G::NT>(q1, sscr, tid);
+            // row means of T on the (sub)grid: thread t sums segment seg of row
+            __syncthreads();
+            {
+                const int row = tid / N2, seg = tid - N2 * row;   // NT = N2*NZ threads: NX/8 = N2 segments of 8 cells per row
+                double s = 0.0;
+                if ((row % stz) == 0)
+                    for (int j = 0; j < 8; ++j) { const int x = 8 * seg + j; if ((x % stx) == 0) s += (double)lane(lds[row * RS + FB + x], e); }
+                sscr[tid] = (scal)s;
+            }
+            __syncthreads();
+            if (tid < NZ) {
+                double s = 0.0;
+                for (int j = 0; j < N2; ++j) s += (double)sscr[tid * N2 + j];
+                sscr[G::NT + 66 + tid] = (scal)(s / (double)mx);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const scal *tx = sscr + G::NT + 66;
+                double g = 0.0;
+                for (int kk = 0; kk < mz; ++kk) {
+                    const double cur = (double)tx[kk * stz];
+                    if (kk == 0) g += (double)tx[stz] - cur;
+                    else if (kk == mz - 1) g += cur - (double)tx[(kk - 1) * stz];
+                    else g += ((double)tx[(kk + 1) * stz] - (double)tx[(kk - 1) * stz]) / 2;
+                }
+                const double q2 = kapd * (g / mz);
+                const double q1m = q1 / ((double)mx * mz);
+                P.nusselt[(size_t)env * 2 + which] = (q1m - q2) / (kapd * P.delta_b / P.lz);
+            }
+            __syncthreads();
+        }
+    }
+    STAMP(0);
+#if RBC_STAMPS
+    if ((tid == 0 || tid == (int)blockDim.x - 1) && P.stamps)
+        for (int j = 0; j < 24; ++j) P.stamps[(size_t)blockIdx.x * 64 + (tid ? 32 : 0) + j] = stamp_acc[j];
+#endif
+    }
 }
 
 // RBCRewardShaping.compute_cell_distances (wrappers/rbc_reward_shaping.py:85-140) for a batch of mid-line signals, one

@@ -68,6 +68,7 @@ struct rbc_handle {
     void (*kernel)(const rbc::Params2D) = nullptr;
     size_t lds_bytes = 0;
     int threads = 0;
+    int lanes = 1;                     // envs per workgroup of the 2D kernel (2 for the packed float32 variant)
 };
 
 #include "rbc3d_host.hpp"
@@ -80,6 +81,7 @@ void bind_kernel(rbc_handle *h)
     h->kernel = rbc::rbc2d_kernel<NX, NZ, T>;
     h->lds_bytes = rbc::Geo<NX, NZ, T>::LDS_BYTES;
     h->threads = rbc::Geo<NX, NZ, T>::NT;
+    h->lanes = rbc::LaneT<T>::N;
 }
 
 // The LDS-resident 2D kernel is instantiated for these grids (x periodic, lanes along x: NX = 8 * {8, 12, 16, 24}; NZ a
@@ -94,6 +96,10 @@ bool bind_grid(rbc_handle *h, int nx, int nz, int precision)
         RBC_GRID(64, 64, double) RBC_GRID(64, 48, double) RBC_GRID(64, 32, double)
         RBC_GRID(128, 32, double)
     } else if (precision == RBC_PRECISION_F32) {
+        // packed pairs (two envs per workgroup, v_pk_*_f32: the f64 kernel's instruction stream at two envs per instruction)
+        // where a pair fits the LDS; RBC_F32_SCALAR=1 selects the one-env-per-workgroup float kernel instead (A/B reference)
+        const char *e = std::getenv("RBC_F32_SCALAR");
+        if (!(e && e[0] == '1')) { RBC_GRID(96, 64, rbc::f32x2) RBC_GRID(64, 64, rbc::f32x2) }
         RBC_GRID(96, 64, float) RBC_GRID(128, 64, float) RBC_GRID(64, 64, float) RBC_GRID(192, 32, float)
     }
 #undef RBC_GRID
@@ -148,6 +154,7 @@ rbc::Params2D base_params(const rbc_handle *h)
     p.min_b = h->cfg.min_b; p.delta_b = h->cfg.delta_b;
     p.heater_limit = h->cfg.heater_limit; p.kick = h->cfg.random_kick;
     p.dt = h->cfg.dt_solver; p.dt_last = h->dt_last; p.nsub = h->nsub;
+    p.batch = h->B;
     p.heaters = h->cfg.heaters;
     p.mode = rbc::MODE_STEP;
     p.write_state = h->cfg.write_state;
@@ -161,7 +168,7 @@ int launch(rbc_handle *h, const rbc::Params2D &p, bool timed)
 {
     const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
     if (rec) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
-    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, p);
+    hipLaunchKernelGGL(h->kernel, dim3((h->B + h->lanes - 1) / h->lanes), dim3(h->threads), h->lds_bytes, h->stream, p);
     HIP_TRY(hipGetLastError());
     if (rec) {
         HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
@@ -815,6 +822,7 @@ int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double
     if (int rc = check_handle(h)) return rc;
     if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_debug_tendencies3");
     if (!actions || !gb || !gu || !gw) return fail(RBC_ERR_INVALID, "null argument");
+    if (h->lanes != 1) return fail(RBC_ERR_INVALID, "rbc_debug_tendencies: not available on the packed float32 kernel (RBC_F32_SCALAR=1 selects the scalar one)");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t nc = h->ncell;
     if (!h->d_dbg) HIP_TRY(hipMalloc(&h->d_dbg, (size_t)h->B * 3 * nc * sizeof(double)));

@@ -321,7 +321,8 @@ def test_unsupported_grids_fail_loudly(native):
 
 # ---------------------------------------------------------------------------------------------
 # float32 variant (rbc_config.precision = RBC_PRECISION_F32).  The reference computes in Float64;
-# this variant keeps float32 state and arithmetic in the kernel (I/O types unchanged).  Stated tolerances, against the
+# this variant keeps float32 state and arithmetic in the kernel (I/O types unchanged; 96x64 and 64x64 run as packed env pairs,
+# an odd batch leaves the last workgroup with one live lane: B = 3 below).  Stated tolerances, against the
 # float64 oracle on identical initial conditions:
 #   one control interval (50 substeps) from a stored Ra=1e4 steady state: rel-L2 < 2e-5 (fields), 1e-4 (Nusselt)
 #   from the chaotic Ra=1e5 state: rel-L2 < 5e-4 (round-off amplified by the flow)
@@ -388,4 +389,51 @@ def test_float32_variant_lands_on_the_reference_attractor(native, golden_dir):
     assert abs(ke[on].mean() - ref["ke_mean"]) < 2e-5 * ref["ke_mean"], (ke[on].mean(), ref["ke_mean"])
     assert abs(nus[on].mean() - ref["nu_state_mean"]) < 2e-4 * ref["nu_state_mean"]
     assert abs(nuo[on].mean() - ref["nu_obs_mean"]) < 2e-4 * ref["nu_obs_mean"]
+    sim.close()
+
+
+def test_float32_packed_and_scalar_kernels_agree_and_pairs_are_independent(native, monkeypatch, ckpt_ra1e4):
+    """The packed float32 kernel (two envs per workgroup in the two halves of every register) against the one-env-per-workgroup
+    float kernel (RBC_F32_SCALAR=1) on the same inputs: same arithmetic per lane up to fma contraction choices (1e-5 rel-L2
+    after 10 substeps); an env's result does not depend on which env shares its workgroup (bitwise); a masked reset of ONE
+    lane of a pair leaves the other lane untouched."""
+    B = 5
+    rng = np.random.default_rng(8)
+    b0 = np.stack([ckpt_ra1e4["b"][e % 3] for e in range(B)]); u0 = np.stack([ckpt_ra1e4["u"][e % 3] for e in range(B)])
+    w0 = np.stack([ckpt_ra1e4["w"][e % 3] for e in range(B)])
+    act = rng.uniform(-1, 1, (B, 12)).astype(np.float32)
+
+    def run(order, scalar):
+        if scalar:
+            monkeypatch.setenv("RBC_F32_SCALAR", "1")
+        else:
+            monkeypatch.delenv("RBC_F32_SCALAR", raising=False)
+        sim = native.NativeSim(batch=B, precision=1, dt_control=0.3)
+        sim.reset_from_arrays(b0[order], u0[order], w0[order])
+        assert sim.step(act[order])
+        out = sim.get_fields() + sim.get_nusselt() + (sim.get_obs(5),)
+        sim.close()
+        inv = np.argsort(order)
+        return [x[inv] for x in out]
+
+    ident = np.arange(B)
+    packed = run(ident, False)
+    scalar = run(ident, True)
+    for x, y in zip(packed[:3], scalar[:3]):
+        assert rel_l2(x, y) < 1e-5
+    assert np.allclose(packed[3], scalar[3], rtol=1e-4) and np.allclose(packed[4], scalar[4], rtol=1e-4)
+    shuffled = run(np.array([3, 0, 4, 2, 1]), False)            # other partners, other lanes, another env alone in the last workgroup
+    for x, y in zip(packed, shuffled):
+        assert np.array_equal(x, y)
+    monkeypatch.delenv("RBC_F32_SCALAR", raising=False)
+    sim = native.NativeSim(batch=4, precision=1, dt_control=0.3)
+    sim.reset_from_arrays(b0[:4], u0[:4], w0[:4])
+    assert sim.step(act[:4])
+    before = sim.get_fields()
+    sim.reset_from_arrays(b0[:4], u0[:4], w0[:4], mask=[0, 1, 0, 0])    # lane 1 of the first pair only
+    after = sim.get_fields()
+    t, s_ = sim.get_info()
+    assert list(s_) == [2, 1, 2, 2]
+    for x, y, z in zip(before, after, (b0, u0, w0)):
+        assert np.array_equal(x[[0, 2, 3]], y[[0, 2, 3]]) and rel_l2(y[1], z[1]) < 1e-5 and not np.array_equal(x[1], y[1])
     sim.close()
