@@ -52,9 +52,11 @@ class RayleighBenardConvection2DEnv(NativeEnvBase):
         checkpoint: Optional[str] = None,
         render_mode: Optional[str] = None,
         device: int = 0,
+        precision: str = "f64",          # "f64": the reference's Float64 arithmetic; "f32": the float32 variant
     ) -> None:
         super().__init__()
         self.ra = rayleigh_number
+        self.precision = precision
         self.observation_shape, self.state_shape = list(observation_shape), list(state_shape)
         self.temperature_difference = [1, 2]                      # plate temperatures fixed by the API layer (rbc_sim2D_api.jl:30-31)
         self.heater_segments, self.heater_limit, self.heater_duration = heater_segments, heater_limit, heater_duration
@@ -65,8 +67,8 @@ class RayleighBenardConvection2DEnv(NativeEnvBase):
         self._channels = 5 if pressure else 3
         self.screen_width, self.screen_height = 768, 512
         self._window = _Window((self.screen_width, self.screen_height), self.metadata["render_fps"])
-        sim = _native.NativeSim(batch=1, device=device, **sim_kwargs(rayleigh_number, self.observation_shape, self.state_shape,
-                                                                     heater_segments, heater_limit, heater_duration))
+        sim = _native.NativeSim(batch=1, device=device, precision=_native.PRECISIONS[precision],
+                                **sim_kwargs(rayleigh_number, self.observation_shape, self.state_shape, heater_segments, heater_limit, heater_duration))
         self._setup(sim, episode_length, checkpoint, render_mode, env_logger(__name__))
 
     # the window handle under the reference's attribute names

@@ -127,7 +127,7 @@ class _BatchedEnv(gym.vector.VectorEnv):
 class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
     def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
                  state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
-                 use_gpu=True, checkpoint=None, render_mode=None, device=0, devices=None, info_state=True, **_ignored):
+                 use_gpu=True, checkpoint=None, render_mode=None, device=0, devices=None, info_state=True, precision="f64", **_ignored):
         # info_state: True = info["state"] is a fresh array every step (the reference's behaviour), "pinned" = it rotates over
         # three page-locked buffers (3x faster device-to-host copy; an array is overwritten three steps later), False = omitted
         self.num_envs = int(num_envs)
@@ -145,6 +145,8 @@ class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
                                                                                heater_limit, pressure)
         ra0 = float(np.asarray(rayleigh_number, dtype=np.float64).ravel()[0])
         kw = sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments, heater_limit, heater_duration)
+        kw["precision"] = _native.PRECISIONS[precision]      # "f32": float32 arithmetic, envs paired up per workgroup
+        self.precision = precision
         # devices=[0, 1, ...]: the envs are split into contiguous ranges, one library handle per GPU (rbc_gym/sharded.py)
         self.devices = None if devices is None else [int(d) for d in devices]
         if self.devices is None:

@@ -557,3 +557,22 @@ def test_running_on_torchs_default_stream_orders_without_explicit_syncs(gym):
         assert np.array_equal(ref.get_obs(5), o)
     sim._check(sim.lib.rbc_set_stream(sim.h, None))                     # back to the own stream
     sim.close(); ref.close()
+
+
+def test_precision_kwarg_selects_the_float32_variant(gym):
+    """`precision="f32"` on the env classes (an extra kwarg; the reference is Float64 only): same API, observations within
+    float32 accuracy of the float64 env over a few control intervals."""
+    n = 3
+    v64 = gym.make_vec(ID, num_envs=n, heater_duration=0.3)
+    v32 = gym.make_vec(ID, num_envs=n, heater_duration=0.3, precision="f32")
+    o64, _ = v64.reset(seed=11); o32, _ = v32.reset(seed=11)
+    assert o32.dtype == np.float32 and np.allclose(o64, o32, atol=2e-6)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        o64, r64, *_ = v64.step(a); o32, r32, *_ = v32.step(a)
+    assert np.allclose(o64, o32, atol=2e-4) and np.allclose(r64, r32, rtol=1e-3, atol=1e-4)
+    e32 = gym.make(ID, heater_duration=0.3, precision="f32")
+    o, _ = e32.reset(seed=11)
+    assert np.array_equal(o, v32.reset(seed=11)[0][0])
+    v64.close(); v32.close(); e32.close()
