@@ -21,6 +21,9 @@ run pmc_fetch --pmc FETCH_SIZE -- $B2
 run pmc_write --pmc WRITE_SIZE -- $B2
 run pmc_sq1 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_BUSY_CYCLES -- $B2
 run pmc_sq2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY -- $B2
+BF="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --precision f32"
+run trace_f32 --stats -- $BF && grep '^{"metric"' "$OUT/trace_f32.log" > "$OUT/bench_trace_f32.log"
+run pmc_f32 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- $BF
 run trace3d --stats -- $B3 && grep '^{"metric"' "$OUT/trace3d.log" > "$OUT/bench_trace3d.log"
 run pmc_fetch3d --pmc FETCH_SIZE -- $B3
 run pmc_write3d --pmc WRITE_SIZE -- $B3

@@ -97,6 +97,29 @@ if ks:
                    "per_launch_mean": sq, "derived": derived}, open(f"{out}/{tag}_sq_counters.json", "w"), indent=1)
         print(json.dumps(derived, indent=1))
 
+# ---------------------------------------------------------------- float32 (packed) variant of the 2D workload
+ksf = one(f"{src}/trace_f32/*/*_kernel_stats.csv")
+if ksf:
+    shutil.copy(ksf, f"{out}/{tag}_f32_kernel_stats.csv")
+    ktf = one(f"{src}/trace_f32/*/*_kernel_trace.csv")
+    rows = [r for r in csv.DictReader(open(ktf)) if "rbc2d_kernel" in r["Kernel_Name"]]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    step = [d for d in dur if d > 0.25 * max(dur)]
+    sq = {}
+    for ctr, per_kernel in counters("pmc_f32", "rbc2d_kernel").items():
+        v = [x for vals in per_kernel.values() for x in vals]
+        v = [x for x in v if x > 0.25 * max(v)] if max(v) > 0 else v
+        sq[ctr] = sum(v) / len(v)
+    ms = sum(step) / len(step)
+    summf = {"workload_key": {"dim": 2, "batch": 1024, "ra": 1e4, "precision": "f32", "ra_sweep": None}, "kernel": rows[0]["Kernel_Name"],
+             "step_launches": len(step), "step_avg_ms": ms, "vgpr": int(rows[0]["VGPR_Count"]), "scratch_bytes_per_lane": int(rows[0]["Scratch_Size"]),
+             "workgroup": int(rows[0]["Workgroup_Size_X"]), "grid": int(rows[0]["Grid_Size_X"]), "sq_per_launch_mean": sq,
+             "bench_line_under_profiler": bench_line(f"{src}/bench_trace_f32.log")}
+    if "SQ_INSTS_VALU" in sq:
+        summf["all_valu_issue_fraction (4 cycles per wave64 instruction)"] = sq["SQ_INSTS_VALU"] * 4 / (1024 * ms * 1e-3 * 2.4e9)
+    json.dump(summf, open(f"{out}/{tag}_f32_summary.json", "w"), indent=1)
+    print(json.dumps({k: v for k, v in summf.items() if k != "bench_line_under_profiler"}, indent=1))
+
 # ---------------------------------------------------------------- 3D configs[4] workload
 ks3 = one(f"{src}/trace3d/*/*_kernel_stats.csv")
 if ks3:
