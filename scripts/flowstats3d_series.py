@@ -4,7 +4,7 @@ number in one batch: Nu(t), max|u|, max|v|, max|w| of the float32 state after ev
 experiments/flowstats/flowstats_ra.py:55-66 records), for the first STEPS steps.  Compared by tests/test_gpu_parity3d.py
 and scripts/flowstats3d_compare.py with the reference's own series (tests/golden/flowstats_ref_series.npz).
 
-    python scripts/flowstats3d_series.py [seeds=16] [steps=100] [out=gpurun_out/flowstats3d_series.npz] [dt_control=0.25] [dt_solver=0.005]
+    python scripts/flowstats3d_series.py [seeds=16] [steps=100] [out=gpurun_out/flowstats3d_series.npz] [dt_control=0.25] [dt_solver=0.005] [lead_substeps=0]
 Needs an MI355X.  RBC_EXPERIMENT_RK3 (see rbc3d_host.hpp) selects deliberately wrong RK3 coefficients for the
 "does the pin discriminate" experiment.
 """
@@ -19,7 +19,12 @@ sys.path.insert(0, os.path.join(ROOT, "rbc-gym_amd"))
 from rbc_gym import _native  # noqa: E402
 
 
-def run_series(ras, seeds, steps, seed0=777, shape=(32, 64, 64), dt_control=0.25, dt_solver=0.005, progress=None):
+def shape_tff(shape, lz=2.0):
+    """free-fall time the 3D API scales its steps with (t_ff = Lz^2, rbc_sim3D_api.jl:43)"""
+    return lz * lz
+
+
+def run_series(ras, seeds, steps, seed0=777, shape=(32, 64, 64), dt_control=0.25, dt_solver=0.005, progress=None, lead_substeps=0):
     """-> dict of arrays [len(ras), seeds, steps]: nusselt, umax, vmax, wmax (flowstats_ra.py:27-36 protocol, zero action)."""
     import torch
     from rbc_gym.vector import DeviceArray
@@ -31,6 +36,8 @@ def run_series(ras, seeds, steps, seed0=777, shape=(32, 64, 64), dt_control=0.25
     nz, ny, nx = shape
     state = torch.as_tensor(DeviceArray(sim.lib.rbc_dev_state(sim.h), (B, 4, nz * ny * nx), "<f4", sim), device="cuda")
     zero = np.zeros((B, 8, 8), np.float32)
+    if lead_substeps:                      # experiment: extra solver steps in front of the first env-step (clock hypotheses)
+        sim.debug_substeps(zero, int(lead_substeps), dt_solver * shape_tff(shape))
     out = {k: np.zeros((R, seeds, steps)) for k in ("nusselt", "umax", "vmax", "wmax")}
     t0 = time.time()
     for n in range(steps):
@@ -52,8 +59,9 @@ if __name__ == "__main__":
     dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "flowstats3d_series.npz")
     dt_control = float(sys.argv[4]) if len(sys.argv) > 4 else 0.25        # experiments only: the protocol's values are the defaults
     dt_solver = float(sys.argv[5]) if len(sys.argv) > 5 else 0.005
+    lead = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     ref = np.load(os.path.join(ROOT, "tests", "golden", "flowstats_ref_series.npz"))
-    out = run_series(ref["ra"], seeds, steps, dt_control=dt_control, dt_solver=dt_solver, progress=lambda s: print(s, flush=True))
+    out = run_series(ref["ra"], seeds, steps, dt_control=dt_control, dt_solver=dt_solver, progress=lambda s: print(s, flush=True), lead_substeps=lead)
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     np.savez_compressed(dst, ra=ref["ra"], **out)
     for i, ra in enumerate(ref["ra"]):
