@@ -12,6 +12,8 @@ struct rbc3_state {
     double *gm = nullptr, *phy = nullptr, *phi = nullptr, *tab = nullptr, *actT = nullptr, *dbg = nullptr;
     double2 *jct = nullptr;            // junction values of the packed z solve, [env][mode]
     double2 *spec = nullptr;
+    double *out_part = nullptr;        // k3_output: per-env partial sums of its OUT_SPLIT workgroups
+    unsigned int *out_arrive = nullptr;
     size_t fft_lds = 0;
     int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
     double tff = 1.0;
@@ -77,6 +79,9 @@ int create3d(rbc_handle *h)
     HIP3(hipMalloc(&s->phi, B * (size_t)g.nc * sizeof(double)));
     HIP3(hipMalloc(&s->spec, B * (size_t)g.nc * sizeof(double2)));
     HIP3(hipMalloc(&s->jct, B * (size_t)g.nx * g.ny * sizeof(double2)));
+    HIP3(hipMalloc(&s->out_part, B * 2 * rbc3::OUT_SPLIT * sizeof(double)));
+    HIP3(hipMalloc(&s->out_arrive, B * sizeof(unsigned int)));
+    HIP3(hipMemset(s->out_arrive, 0, B * sizeof(unsigned int)));
     HIP3(hipMalloc(&s->actT, B * (size_t)c.heaters * c.heaters * sizeof(double)));
     HIP3(hipMemset(s->actT, 0, B * (size_t)c.heaters * c.heaters * sizeof(double)));
     {   // pivots of the z operator for every horizontal mode: tab[k][n][m] = 1/piv_k
@@ -110,7 +115,7 @@ void destroy3d(rbc_handle *h)
     if (!s) return;
     for (auto &g : s->gexec)
         if (g) (void)hipGraphExecDestroy(g);
-    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->actT, s->tab, s->dbg};
+    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -151,7 +156,8 @@ int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
 int output3d(rbc_handle *h, const uint8_t *mask)
 {
     rbc3_state *s = h->s3;
-    hipLaunchKernelGGL(rbc3::k3_output, dim3(h->B), dim3(256), 0, h->stream, s->g, s->st[s->cur], h->d_ra, h->d_state, h->d_nu, h->d_flags, mask);
+    hipLaunchKernelGGL(rbc3::k3_output, dim3(h->B * rbc3::OUT_SPLIT), dim3(256), 0, h->stream, s->g, s->st[s->cur], h->d_ra, h->d_state, h->d_nu, h->d_flags, mask,
+                       s->out_part, s->out_arrive);
     HIP3(hipGetLastError());
     return RBC_OK;
 }
@@ -179,15 +185,13 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
             if (!tiled)                                        // the fallback kernels use the hydrostatic split (pHY' column scan)
                 hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
             if (tiles_fit(16, 4, 768)) {                       // LDS-tiled kernels: planes staged once per level
-                const dim3 gt((unsigned)((size_t)B * (g.ny / 16) * (g.nz / 4))), bt(g.nx * 16);
+                const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / 16) * (g.nz / 4))), bt(g.nx * 16);      // first half: (u, v), second half: (w, b)
                 const size_t pb = (size_t)(16 + 6) * rbc3::NXP3 * sizeof(double);
-                hipLaunchKernelGGL((rbc3::k3_tile_uv<16, 4, 2, 768, 3>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, h->d_ra, d, gam[ph], zet[ph], store_g);
-                hipLaunchKernelGGL((rbc3::k3_tile_wb<16, 4, 2, 768, 3>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
+                hipLaunchKernelGGL((rbc3::k3_tile_all<16, 4, 2, 768, 3>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
             } else if (tiles_fit(8, 8, 512)) {
-                const dim3 gt((unsigned)((size_t)B * (g.ny / 8) * (g.nz / 8))), bt(g.nx * 8);
+                const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / 8) * (g.nz / 8))), bt(g.nx * 8);
                 const size_t pb = (size_t)(8 + 6) * rbc3::NXP3 * sizeof(double);
-                hipLaunchKernelGGL((rbc3::k3_tile_uv<8, 8, 2, 512, 2>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, h->d_ra, d, gam[ph], zet[ph], store_g);
-                hipLaunchKernelGGL((rbc3::k3_tile_wb<8, 8, 2, 512, 2>), gt, bt, 2 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
+                hipLaunchKernelGGL((rbc3::k3_tile_all<8, 8, 2, 512, 2>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
             } else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
                 const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
                 hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);

@@ -73,19 +73,23 @@ __device__ __forceinline__ double bottom_T(const Geo3 &g, const double *act, int
 }
 
 // ---- preprocess_action, rbc_sim3D.jl:111-128: act_T[env][n*n] -----------------------------------
-__global__ void k3_preprocess(Geo3 g, const float *actions, double *actT, int raw_zero)
+__global__ void __launch_bounds__(64) k3_preprocess(Geo3 g, const float *actions, double *actT, int raw_zero)
 {
-    const int env = blockIdx.x, nn = g.heaters * g.heaters;
-    if (threadIdx.x != 0) return;
+    const int env = blockIdx.x, nn = g.heaters * g.heaters, lane = threadIdx.x;
     double *o = actT + (size_t)env * nn;
-    if (raw_zero || actions == nullptr) { for (int a = 0; a < nn; ++a) o[a] = 0.0; return; }
+    if (raw_zero || actions == nullptr) { for (int a = lane; a < nn; a += 64) o[a] = 0.0; return; }
     const float *in = actions + (size_t)env * nn;
-    double mean = 0.0, mx = 0.0;
-    for (int a = 0; a < nn; ++a) mean += (double)in[a];
-    mean /= nn;
-    for (int a = 0; a < nn; ++a) mx = fmax(mx, fabs((double)in[a] - mean));
-    const double K = mx > 1.0 ? mx : 1.0;
-    for (int a = 0; a < nn; ++a) o[a] = (g.min_b + g.delta_b) + (((double)in[a] - mean) / K) * g.heater_limit;
+    __shared__ double sh[2];
+    if (lane == 0) {                       // the two reductions stay serial in index order (same sums as the oracle, bit for bit)
+        double mean = 0.0, mx = 0.0;
+        for (int a = 0; a < nn; ++a) mean += (double)in[a];
+        mean /= nn;
+        for (int a = 0; a < nn; ++a) mx = fmax(mx, fabs((double)in[a] - mean));
+        sh[0] = mean; sh[1] = mx > 1.0 ? mx : 1.0;
+    }
+    __syncthreads();
+    const double mean = sh[0], K = sh[1];
+    for (int a = lane; a < nn; a += 64) o[a] = (g.min_b + g.delta_b) + (((double)in[a] - mean) / K) * g.heater_limit;
 }
 
 // ---- hydrostatic pressure anomaly: thread per column --------------------------------------------
@@ -448,11 +452,11 @@ template <int TY3, int KT3>
 struct TileGeo {
     static constexpr int PLANE3 = (TY3 + 6) * NXP3;
     int nx, ny, nz, pl, rows, plane, tiles, chunks, env, j0, k0, i, jl, j, tid, nthreads;
-    __device__ __forceinline__ TileGeo(const Geo3 &g)
+    __device__ __forceinline__ TileGeo(const Geo3 &g, int blk)
     {
         nx = g.nx; ny = g.ny; nz = g.nz; pl = nx * ny; rows = TY3 + 6; plane = rows * nx;
         tiles = ny / TY3; chunks = nz / KT3;
-        const int blk = blockIdx.x, zc = blk % chunks, yt = (blk / chunks) % tiles;
+        const int zc = blk % chunks, yt = (blk / chunks) % tiles;
         env = blk / (chunks * tiles); j0 = yt * TY3; k0 = zc * KT3;
         tid = threadIdx.x; nthreads = blockDim.x; jl = tid / nx; i = tid - jl * nx; j = j0 + jl;
     }
@@ -481,15 +485,15 @@ __device__ __forceinline__ void tile_store(const TG &t, double *dst, const doubl
     }
 }
 
-// (u, v): launch with blockDim = nx * TY3, grid = B * (ny/TY3) * (nz/KT3), LDS = 3 planes.  Two shapes are built:
+// (u, v): blockDim = nx * TY3, B * (ny/TY3) * (nz/KT3) workgroups, LDS = 3 planes.  Two shapes are built:
 // 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
 // (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
-template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
-__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *cur, double *nxt, double *gm,
-                                                  const double *nu_kappa, double dt, double gam, double zet, int store_g)
+template <int TY3, int KT3, int NPF>
+__device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, double *nxt, double *gm,
+                                             const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo<TY3, KT3> t(g);
+    const TileGeo<TY3, KT3> t(g, blk);
     constexpr int PLANE3 = TileGeo<TY3, KT3>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PU = tile_sm, *PV = tile_sm + PLANE3, *PW = tile_sm + 2 * PLANE3;        // u(k), v(k), w(k+1)
@@ -618,13 +622,13 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_uv(Geo3 g, const double *
     }
 }
 
-// (w, b): same launch shape, LDS = 2 planes (w and b at the current level)
-template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
-__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
-                                                  const double *nu_kappa, double dt, double gam, double zet, int store_g)
+// (w, b): same shape, LDS = 2 planes (w and b at the current level)
+template <int TY3, int KT3, int NPF>
+__device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, double *nxt, double *gm, const double *actT,
+                                             const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo<TY3, KT3> t(g);
+    const TileGeo<TY3, KT3> t(g, blk);
     constexpr int PLANE3 = TileGeo<TY3, KT3>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PW = tile_sm, *PB = tile_sm + PLANE3;
@@ -739,6 +743,19 @@ __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_wb(Geo3 g, const double *
         }
     }
     if (t.k0 + KT3 == nz) nxt[eb + 3 * (size_t)g.nc + (size_t)nz * pl + col] = 0.0;      // top wall face
+}
+
+// Both tendency kernels as ONE launch: the first half of the grid runs the (u, v) body, the second half the (w, b) body (they
+// read the same state buffer and write disjoint fields).  A kernel boundary on the dependent stream costs about 10 us on this
+// path whatever the kernels do (2.5 ms per env-step at B = 1, where all 234 launches are nearly empty); one launch fewer per
+// stage is worth more here than anything done inside the kernels.
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
+__global__ void __launch_bounds__(MAXT, WAVES) k3_tile_all(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
+                                                   const double *nu_kappa, double dt, double gam, double zet, int store_g)
+{
+    const int half = gridDim.x >> 1;                 // first half of the grid: (u, v); second half: (w, b), starting as the first drains
+    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half);
+    else tile_uv_body<TY3, KT3, NPF>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x);
 }
 
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------
@@ -1229,21 +1246,26 @@ __global__ void k3_random(Geo3 g, double *st, const uint64_t *seeds, const uint8
     }
 }
 
-// outputs: float32 state (b,u,v,w), Nusselt (rbc_sim3D_api.jl:134-159), NaN flag.  One workgroup per env.
-__global__ void k3_output(Geo3 g, const double *st, const double *nu_kappa, float *state32, double *nusselt, int *flags, const uint8_t *mask)
+// outputs: float32 state (b,u,v,w), Nusselt (rbc_sim3D_api.jl:134-159), NaN flag.  OUT_SPLIT workgroups per env, each over a
+// contiguous share of the cells; the partial sums meet in `part` and the workgroup that arrives last (a counter per env) adds
+// them in index order, so the result does not depend on the arrival order (bitwise reproducible).
+constexpr int OUT_SPLIT = 16;
+__global__ void __launch_bounds__(256) k3_output(Geo3 g, const double *st, const double *nu_kappa, float *state32, double *nusselt, int *flags,
+                                                 const uint8_t *mask, double *part, unsigned int *arrive)
 {
     __shared__ double red[256];
-    __shared__ int bad;
-    const int env = blockIdx.x;
+    __shared__ int bad, last;
+    const int env = blockIdx.x / OUT_SPLIT, sp = blockIdx.x - env * OUT_SPLIT;
     if (mask && !mask[env]) return;
     const double *sb = st + (size_t)env * g.env_stride;
     const int pln = g.nx * g.ny;
-    if (threadIdx.x == 0) bad = 0;
+    if (threadIdx.x == 0) { bad = 0; last = 0; }
     __syncthreads();
     double acc = 0.0;
     int nan = 0;
     float *o = state32 + (size_t)env * 4 * g.nc;
-    for (int c0 = threadIdx.x; c0 < g.nc; c0 += blockDim.x) {
+    const int per = (g.nc + OUT_SPLIT - 1) / OUT_SPLIT, c_end = min(g.nc, (sp + 1) * per);
+    for (int c0 = sp * per + threadIdx.x; c0 < c_end; c0 += blockDim.x) {
         const int k = c0 / pln;
         const double b = sb[c0], u = sb[g.nc + c0], v = sb[2 * (size_t)g.nc + c0], w = sb[3 * (size_t)g.nc + c0];
         o[c0] = (float)b; o[g.nc + c0] = (float)u; o[2 * (size_t)g.nc + c0] = (float)v; o[3 * (size_t)g.nc + c0] = (float)w;
@@ -1257,8 +1279,20 @@ __global__ void k3_output(Geo3 g, const double *st, const double *nu_kappa, floa
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int t = 0; t < (int)blockDim.x; ++t) s += red[t];
-        nusselt[env] = 1.0 + (s / (double)g.nc) / nu_kappa[2 * env + 1];
-        flags[env] = bad;
+        part[(size_t)env * 2 * OUT_SPLIT + sp] = s;
+        part[(size_t)env * 2 * OUT_SPLIT + OUT_SPLIT + sp] = bad ? 1.0 : 0.0;
+        __threadfence();
+        if (atomicAdd(&arrive[env], 1u) == OUT_SPLIT - 1) {       // every share of this env is in
+            __threadfence();
+            double tot = 0.0, anybad = 0.0;
+            for (int q = 0; q < OUT_SPLIT; ++q) {
+                tot += __builtin_nontemporal_load(&part[(size_t)env * 2 * OUT_SPLIT + q]);
+                anybad += __builtin_nontemporal_load(&part[(size_t)env * 2 * OUT_SPLIT + OUT_SPLIT + q]);
+            }
+            nusselt[env] = 1.0 + (tot / (double)g.nc) / nu_kappa[2 * env + 1];
+            flags[env] = anybad > 0.0 ? 1 : 0;
+            arrive[env] = 0;                                       // ready for the next call
+        }
     }
 }
 
