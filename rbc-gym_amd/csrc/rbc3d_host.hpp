@@ -48,15 +48,19 @@ int create3d(rbc_handle *h)
     auto *s = new rbc3_state();
     h->s3 = s;
     rbc3::Geo3 &g = s->g;
-    g.nx = c.nx; g.ny = c.ny; g.nz = c.nz;
-    g.nc = c.nx * c.ny * c.nz; g.nw = c.nx * c.ny * (c.nz + 1);
+    // streaming-2D mode (a dim = 2 handle on a grid the LDS-resident kernel is not built for): ny = 1, see rbc3d_kernels.hpp
+    const int ny = h->stream2d ? 1 : c.ny;
+    const double ly = h->stream2d ? 1.0 : c.ly;
+    g.nx = c.nx; g.ny = ny; g.nz = c.nz;
+    g.nc = c.nx * ny * c.nz; g.nw = c.nx * ny * (c.nz + 1);
     g.env_stride = (size_t)3 * g.nc + g.nw;
-    g.lx = c.lx; g.ly = c.ly; g.lz = c.lz;
-    g.dx = c.lx / c.nx; g.dy = c.ly / c.ny; g.dz = c.lz / c.nz;
+    g.lx = c.lx; g.ly = ly; g.lz = c.lz;
+    g.dx = c.lx / c.nx; g.dy = ly / ny; g.dz = c.lz / c.nz;
     g.rdx = 1.0 / g.dx; g.rdy = 1.0 / g.dy; g.rdz = 1.0 / g.dz;
     g.min_b = c.min_b; g.delta_b = c.delta_b; g.heater_limit = c.heater_limit; g.kick = c.random_kick;
     g.heaters = c.heaters;
-    s->tff = c.lz * c.lz;                                    // rbc_sim3D_api.jl:43
+    g.wall_nx = h->stream2d ? c.nx : 0;
+    s->tff = h->stream2d ? 1.0 : c.lz * c.lz;                // rbc_sim3D_api.jl:43
     if (const char *e = std::getenv("RBC_EXPERIMENT_RK3")) {
         double v[5];
         if (std::sscanf(e, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
@@ -64,9 +68,9 @@ int create3d(rbc_handle *h)
         } else return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_RK3 must be g1,g2,g3,z2,z3");
     }
     factor2(c.nx, s->plan.nx1, s->plan.nx2);
-    factor2(c.ny, s->plan.ny1, s->plan.ny2);
-    s->fft_lds = ((size_t)2 * c.nx * c.ny + c.nx + c.ny) * sizeof(double2);
-    { const int items = 8 * (c.nx > c.ny ? c.nx : c.ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
+    factor2(ny, s->plan.ny1, s->plan.ny2);
+    s->fft_lds = ((size_t)2 * c.nx * ny + c.nx + ny) * sizeof(double2);
+    { const int items = 8 * (c.nx > ny ? c.nx : ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
     const size_t B = h->B;
     for (int q = 0; q < 2; ++q) {
@@ -82,21 +86,22 @@ int create3d(rbc_handle *h)
     HIP3(hipMalloc(&s->out_part, B * 2 * rbc3::OUT_SPLIT * sizeof(double)));
     HIP3(hipMalloc(&s->out_arrive, B * sizeof(unsigned int)));
     HIP3(hipMemset(s->out_arrive, 0, B * sizeof(unsigned int)));
-    HIP3(hipMalloc(&s->actT, B * (size_t)c.heaters * c.heaters * sizeof(double)));
-    HIP3(hipMemset(s->actT, 0, B * (size_t)c.heaters * c.heaters * sizeof(double)));
+    const size_t nwall = h->stream2d ? (size_t)c.nx : (size_t)c.heaters * c.heaters;     // bottom-plate table per env
+    HIP3(hipMalloc(&s->actT, B * nwall * sizeof(double)));
+    HIP3(hipMemset(s->actT, 0, B * nwall * sizeof(double)));
     {   // pivots of the z operator for every horizontal mode: tab[k][n][m] = 1/piv_k
         const double o = 1.0 / (g.dz * g.dz), pi = 3.14159265358979323846;
         std::vector<double> tab((size_t)g.nc);
-        for (int n = 0; n < c.ny; ++n)
+        for (int n = 0; n < ny; ++n)
             for (int m = 0; m < c.nx; ++m) {
-                const double tx = 2.0 * std::sin(m * pi / c.nx) / g.dx, ty = 2.0 * std::sin(n * pi / c.ny) / g.dy;
+                const double tx = 2.0 * std::sin(m * pi / c.nx) / g.dx, ty = 2.0 * std::sin(n * pi / ny) / g.dy;
                 const double lam = tx * tx + ty * ty;
                 double piv = 0.0;
                 for (int k = 0; k < c.nz; ++k) {
                     double d = -((k == 0 || k == c.nz - 1) ? 1.0 : 2.0) * o - lam;
                     if (m == 0 && n == 0 && k == c.nz - 1) d -= o;       // pin the singular mean mode
                     piv = (k == 0) ? d : d - o * o / piv;
-                    tab[((size_t)k * c.ny + n) * c.nx + m] = 1.0 / piv;
+                    tab[((size_t)k * ny + n) * c.nx + m] = 1.0 / piv;
                 }
             }
         HIP3(hipMalloc(&s->tab, tab.size() * sizeof(double)));
@@ -156,10 +161,31 @@ int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
 int output3d(rbc_handle *h, const uint8_t *mask)
 {
     rbc3_state *s = h->s3;
+    if (h->stream2d) {
+        rbc3::Out2D o{};
+        o.obs = h->d_obs; o.state32 = h->d_state; o.nusselt = h->d_nu; o.flags = h->d_flags;
+        o.obs_nx = h->cfg.obs_nx; o.obs_nz = h->cfg.obs_nz; o.write_state = h->cfg.write_state;
+        o.obs_norm = h->obs_norm; o.obs_clip = h->obs_clip; o.obs_maxval = h->obs_maxval;
+        for (int c = 0; c < 5; ++c) { o.obs_min[c] = h->obs_min[c]; o.obs_rng[c] = h->obs_rng[c]; }
+        hipLaunchKernelGGL(rbc3::k2s_output, dim3(h->B), dim3(256), (2 * (size_t)s->g.nz + 256) * sizeof(double), h->stream, s->g, s->st[s->cur], s->phi,
+                           h->d_ra, o, mask);
+        HIP3(hipGetLastError());
+        return RBC_OK;
+    }
     hipLaunchKernelGGL(rbc3::k3_output, dim3(h->B * rbc3::OUT_SPLIT), dim3(256), 0, h->stream, s->g, s->st[s->cur], h->d_ra, h->d_state, h->d_nu, h->d_flags, mask,
                        s->out_part, s->out_arrive);
     HIP3(hipGetLastError());
     return RBC_OK;
+}
+
+// bottom-plate table of every env from the raw actions: preprocess_action (3D) / collate_actions_colin per column (streaming 2D)
+void wall3d(rbc_handle *h, const float *actions_dev, int zero)
+{
+    rbc3_state *s = h->s3;
+    if (h->stream2d)
+        hipLaunchKernelGGL(rbc3::k2s_wall, grid_for((size_t)h->B * s->g.nx, 128), dim3(128), 0, h->stream, s->g, actions_dev, s->actT, zero, h->B);
+    else
+        hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(h->B), dim3(64), 0, h->stream, s->g, actions_dev, s->actT, zero);
 }
 
 // one stage list for `nsub` substeps (the last of size dt_last); actions already on the device
@@ -168,7 +194,7 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
     rbc3_state *s = h->s3;
     const rbc3::Geo3 &g = s->g;
     const int B = h->B;
-    hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(B), dim3(64), 0, h->stream, g, actions_dev, s->actT, 0);
+    wall3d(h, actions_dev, 0);
     const double *gam = s->gam, *zet = s->zet;
     const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
     for (int n = 0; n < nsub; ++n) {
@@ -218,7 +244,7 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
     const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
     const bool standard = (nsub == h->nsub) && (dt == h->dt_solver_eff) && (dt_last == h->dt_last) && !h->no_graph;
     if (standard && actions_dev != h->d_actions)     // the graph reads the handle's own action buffer
-        HIP3(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->B * s->g.heaters * s->g.heaters * sizeof(float),
+        HIP3(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->B * (h->stream2d ? 1 : s->g.heaters) * s->g.heaters * sizeof(float),
                             hipMemcpyDeviceToDevice, h->stream));
     if (rec) HIP3(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
     if (standard) {
@@ -252,7 +278,7 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
 int finish_reset3d(rbc_handle *h)
 {
     rbc3_state *s = h->s3;
-    hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(h->B), dim3(64), 0, h->stream, s->g, (const float *)nullptr, s->actT, 1);
+    wall3d(h, nullptr, 1);
     if (int rc = project3d(h, s->st[s->cur], 1.0, h->d_mask)) return rc;
     if (int rc = output3d(h, h->d_mask)) return rc;
     HIP3(hipStreamSynchronize(h->stream));

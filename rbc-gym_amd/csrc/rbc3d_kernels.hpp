@@ -26,6 +26,8 @@ struct Geo3 {
     double dx, dy, dz, rdx, rdy, rdz, lx, ly, lz;
     double min_b, delta_b, heater_limit, kick;
     int heaters;
+    int wall_nx;       // 0: the 3D envs' heaters x heaters table (bottom_T below); > 0: streaming-2D mode (ny = 1), the bottom-plate
+                       // temperature is a per-column table of wall_nx values per env (collate_actions_colin, k2s_wall)
 };
 
 __device__ __forceinline__ double upw(double vel, double L, double R) { return vel * (vel > 0.0 ? L : R); }
@@ -33,8 +35,13 @@ __device__ __forceinline__ double upw(double vel, double L, double R) { return v
 // periodic 7-point index table around i
 __device__ __forceinline__ void wrap7(int i, int n, int *o)
 {
+    if (n >= 3) {
 #pragma unroll
-    for (int d = -3; d <= 3; ++d) { int t = i + d; t += (t < 0) ? n : 0; t -= (t >= n) ? n : 0; o[d + 3] = t; }
+        for (int d = -3; d <= 3; ++d) { int t = i + d; t += (t < 0) ? n : 0; t -= (t >= n) ? n : 0; o[d + 3] = t; }
+    } else {               // ny = 1 (streaming-2D mode) or 2: more than one wrap
+#pragma unroll
+        for (int d = -3; d <= 3; ++d) { int t = (i + d) % n; o[d + 3] = t + ((t < 0) ? n : 0); }
+    }
 }
 
 // z (Bounded, N cells).  centre field -> face k: p[j] = psi[k-3+j], j=0..5 (face between p[2] | p[3])
@@ -63,8 +70,10 @@ struct Fields {
 };
 
 // wall temperature of column (i,j): bottom_T, rbc_sim3D.jl:131-141 (act = preprocessed 8x8 table)
+__device__ __forceinline__ size_t wall_stride(const Geo3 &g) { return g.wall_nx ? (size_t)g.wall_nx : (size_t)g.heaters * g.heaters; }
 __device__ __forceinline__ double bottom_T(const Geo3 &g, const double *act, int i, int j)
 {
+    if (g.wall_nx) return act[i];
     const int n = g.heaters;
     const double x = (i + 0.5) * g.dx, y = (j + 0.5) * g.dy;
     int a = (int)floor(x / g.lx * n) + 1, c = (int)floor(y / g.ly * n) + 1;
@@ -265,7 +274,7 @@ __global__ void k3_tendency(Geo3 g, const double *cur, double *nxt, double *gm, 
         const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fb) * rdz;
         const double b0 = A(b, 0, 0, k);
         const double bup = (k + 1 < nz) ? A(b, 0, 0, k + 1) : ghost_hi(b0, g.min_b);
-        const double bdn = (k > 0) ? A(b, 0, 0, k - 1) : ghost_lo(b0, bottom_T(g, actT + (size_t)env * g.heaters * g.heaters, i, j));
+        const double bdn = (k > 0) ? A(b, 0, 0, k - 1) : ghost_lo(b0, bottom_T(g, actT + (size_t)env * wall_stride(g), i, j));
         const double dif = ka * (((A(b, 1, 0, k) - b0) - (b0 - A(b, -1, 0, k))) * rdx * rdx
                                  + ((A(b, 0, 1, k) - b0) - (b0 - A(b, 0, -1, k))) * rdy * rdy
                                  + ((bup - b0) - (b0 - bdn)) * rdz * rdz);
@@ -408,7 +417,7 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
         double win[6];
         for (int q = 0; q < 6; ++q) win[q] = Zc(b, 0, 0, k0 - 3 + q);
         double fb = (k0 > 0) ? upw(A(w, 0, 0, k0), zfL(win, k0, nz), zfR(win, k0, nz)) : 0.0;
-        double bdn = (k0 > 0) ? win[2] : ghost_lo(win[3], bottom_T(g, actT + (size_t)env * g.heaters * g.heaters, i, j));
+        double bdn = (k0 > 0) ? win[2] : ghost_lo(win[3], bottom_T(g, actT + (size_t)env * wall_stride(g), i, j));
         for (int k = k0; k < k0 + KC3; ++k) {
             for (int q = 0; q < 5; ++q) win[q] = win[q + 1];
             win[5] = Zc(b, 0, 0, k + 3);
@@ -669,7 +678,7 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
     double ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0, ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : 0.0;
     double fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : 0.0;
     double fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : 0.0;
-    double bdn = (t.k0 > 0) ? winb[2] : ghost_lo(winb[3], bottom_T(g, actT + (size_t)t.env * g.heaters * g.heaters, t.i, t.j));
+    double bdn = (t.k0 > 0) ? winb[2] : ghost_lo(winb[3], bottom_T(g, actT + (size_t)t.env * wall_stride(g), t.i, t.j));
     tile_store(t, PW, pfw); tile_store(t, PB, pfb);
     __syncthreads();
 
@@ -1293,6 +1302,162 @@ __global__ void __launch_bounds__(256) k3_output(Geo3 g, const double *st, const
             flags[env] = anybad > 0.0 ? 1 : 0;
             arrive[env] = 0;                                       // ready for the next call
         }
+    }
+}
+
+// =====================================================================================================================
+// Streaming-2D mode: 2D grids whose state does not fit a CU's LDS (float64: 128x64, 192x32, ... any nx, nz the slab FFT
+// and the z kernels take) run on the 3D streaming kernels above with ny = 1: every y-neighbour of a cell is the cell itself,
+// so all y-fluxes, the y-viscous terms and the y-pressure gradient vanish identically, v stays exactly 0 and the (x, z)
+// operators are the 2D ones (tests/test_oracle3d.py pins a y-independent 3D state on the 2D oracle; here ny = 1 makes it
+// exact and removes the 3D instability of 2D rolls).  What differs from a 3D env is supplied here: the heater profile
+// (collate_actions_colin), the 2D random initial condition, and the 2D outputs (5-channel float32 state / observations,
+// the two Nusselt numbers of rbc_sim2D_api.jl:142-163).
+// =====================================================================================================================
+
+// bottom-plate temperature of every column: collate_actions_colin (rbc_sim2D.jl:87-133), same arithmetic as rbc2d_kernel
+__global__ void __launch_bounds__(128) k2s_wall(Geo3 g, const float *actions, double *wall, int zero_action, int B)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.nx * B) return;
+    const int env = t / g.nx, i = t - env * g.nx;
+    const int n = g.heaters;
+    const double ampl = g.heater_limit, hdx = 0.03;
+    const float *act = (zero_action || actions == nullptr) ? nullptr : actions + (size_t)env * n;
+    double mean = 0.0, dev = 0.0;
+    for (int a = 0; a < n; ++a) mean += ampl * (act ? (double)act[a] : 0.0);
+    mean /= n;
+    for (int a = 0; a < n; ++a) dev = fmax(dev, fabs(ampl * (act ? (double)act[a] : 0.0) - mean));
+    double K2 = dev / ampl;
+    if (!(K2 > 1.0)) K2 = 1.0;
+    const double seg = g.lx / n, x = (i + 0.5) * g.dx;
+    int xs = (int)floor(x / seg) + 1;
+    if (xs > n) xs = n;
+    const int a0 = (xs == 1) ? n : xs - 1, a2 = (xs == n) ? 1 : xs + 1;
+    const double T0 = 2 + (ampl * (act ? (double)act[a0 - 1] : 0.0) - mean) / K2;
+    const double T1 = 2 + (ampl * (act ? (double)act[xs - 1] : 0.0) - mean) / K2;
+    const double T2 = 2 + (ampl * (act ? (double)act[a2 - 1] : 0.0) - mean) / K2;
+    const double xp = x - (xs - 1) * seg;
+    double Tb;
+    if (xp < hdx) Tb = T0 + ((T0 - T1) / (4 * hdx * hdx * hdx)) * (xp - 2 * hdx) * (xp + hdx) * (xp + hdx);
+    else if (xp >= seg - hdx) Tb = T1 + ((T1 - T2) / (4 * hdx * hdx * hdx)) * (xp - seg - 2 * hdx) * (xp - seg + hdx) * (xp - seg + hdx);
+    else Tb = T1;
+    wall[(size_t)env * g.nx + i] = Tb;
+}
+
+// random IC of the 2D envs: initialize_model, rbc_sim2D.jl:163-171, with the 2D kernel's counters (fields 0:u 1:w 2:b, index k*nx+i)
+__global__ void k2s_random(Geo3 g, double *st, const uint64_t *seeds, const uint8_t *mask, int B)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= g.nc * B) return;
+    const int env = cell / g.nc, c0 = cell - env * g.nc;
+    if (mask && !mask[env]) return;
+    const int k = c0 / g.nx;
+    double *sb = st + (size_t)env * g.env_stride;
+    const uint64_t seed = seeds[env];
+    sb[g.nc + c0] = g.kick * rbc::normal_deviate(seed, 0, (uint32_t)c0);                       // u
+    sb[2 * (size_t)g.nc + c0] = 0.0;                                                           // v
+    sb[3 * (size_t)g.nc + c0] = (k == 0) ? 0.0 : g.kick * rbc::normal_deviate(seed, 1, (uint32_t)c0);   // w (wall face 0)
+    if (k == g.nz - 1) sb[3 * (size_t)g.nc + c0 + g.nx] = 0.0;                                 // top wall face
+    const double z = (k + 0.5) * g.dz;
+    const double val = g.min_b + (g.lz - z) * g.delta_b / 2 + g.kick * rbc::normal_deviate(seed, 2, (uint32_t)c0);
+    sb[c0] = fmin(fmax(val, g.min_b), g.min_b + g.delta_b);
+}
+
+struct Out2D {
+    float *obs, *state32;       // [B][5][obs_nz][obs_nx], [B][5][nz][nx]
+    double *nusselt;            // [B][2]
+    int *flags;
+    int obs_nx, obs_nz, write_state, obs_norm, obs_clip;
+    float obs_min[5], obs_rng[5], obs_maxval;
+};
+
+__device__ __forceinline__ float obs_value2(const Out2D &P, int c, double x)
+{
+    float o = (float)x;
+    if (c < P.obs_norm) {      // RBCNormalizeObservation, same float32 operations as rbc::obs_value
+        o = __fmul_rn(P.obs_maxval, __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(o, P.obs_min[c])), P.obs_rng[c]), 1.0f));
+        if (P.obs_clip) o = fminf(fmaxf(o, -P.obs_maxval), P.obs_maxval);
+    }
+    return o;
+}
+
+// 2D outputs of one env per workgroup (256 threads; serial sums in index order: deterministic): channels b,u,w,pHY',pNHS as
+// float32 state and strided observations (rbc_sim2D_api.jl:102-129), Nusselt numbers on the state and on the sensor grid
+// (:142-163 with array_gradient, rbc_sim2D.jl:206-220), NaN flag.  phi = the last stage's potential (its mean removed).
+__global__ void __launch_bounds__(256) k2s_output(Geo3 g, const double *st, const double *phi, const double *nu_kappa, Out2D P, const uint8_t *mask)
+{
+    extern __shared__ double sm2[];          // [nz] row means (state grid) | [nz] scratch | [256] reduction
+    const int env = blockIdx.x, tid = threadIdx.x, nx = g.nx, nz = g.nz, nc = g.nc;
+    if (mask && !mask[env]) return;
+    double *rowmean = sm2, *red = sm2 + 2 * nz;
+    const double *sb = st + (size_t)env * g.env_stride;
+    const double *b = sb, *u = sb + nc, *w = sb + 3 * (size_t)nc, *ph = phi + (size_t)env * nc;
+    const double kap = nu_kappa[2 * env + 1];
+    auto block_sum = [&](double v) -> double {
+        __syncthreads();
+        red[tid] = v;
+        __syncthreads();
+        if (tid == 0) { double s = 0.0; for (int t = 0; t < 256; ++t) s += red[t]; red[0] = s; }
+        __syncthreads();
+        const double r = red[0];
+        return r;
+    };
+    // NaN flag + mean of phi
+    double bad = 0.0, psum = 0.0;
+    for (int c = tid; c < nc; c += 256) { bad += (isnan(b[c]) || isnan(u[c]) || isnan(w[c])) ? 1.0 : 0.0; psum += ph[c]; }
+    bad = block_sum(bad);
+    psum = block_sum(psum);
+    if (tid == 0) P.flags[env] = bad > 0.0 ? 1 : 0;
+    const double pmean = psum / (double)nc;
+    // float32 state + observations; pHY' by a column scan from the top (thread per column)
+    const int stx = nx / P.obs_nx, stz = nz / P.obs_nz;
+    float *ob = P.obs + (size_t)env * 5 * P.obs_nz * P.obs_nx, *sbf = P.state32 + (size_t)env * 5 * nc;
+    const size_t och = (size_t)P.obs_nz * P.obs_nx;
+    const double hz = g.dz / 2;
+    for (int i = tid; i < nx; i += 256) {
+        double up = 0.0, acc = 0.0;
+        for (int k = nz - 1; k >= 0; --k) {
+            const int c = k * nx + i;
+            const double bc = b[c];
+            const double above = (k == nz - 1) ? (bc + ((g.min_b - bc) / hz) * g.dz) : up;      // Value-BC halo above the top cell
+            acc = acc - (0.5 * (bc + above)) * g.dz;
+            up = bc;
+            const double vals[5] = {bc, u[c], w[c], acc, ph[c] - pmean};
+            if (P.write_state)
+                for (int q = 0; q < 5; ++q) sbf[(size_t)q * nc + c] = (float)vals[q];
+            if ((i % stx) == 0 && (k % stz) == 0) {
+                const size_t o = (size_t)(k / stz) * P.obs_nx + (i / stx);
+                for (int q = 0; q < 5; ++q) ob[q * och + o] = obs_value2(P, q, vals[q]);
+            }
+        }
+    }
+    // Nusselt numbers
+    for (int which = 0; which < 2; ++which) {
+        const int sx = which ? stx : 1, sz = which ? stz : 1;
+        const int mx = nx / sx, mz = nz / sz;
+        double q1 = 0.0;
+        for (int c = tid; c < nc; c += 256) { const int k = c / nx, i = c - k * nx; if ((i % sx) == 0 && (k % sz) == 0) q1 += b[c] * w[c]; }
+        q1 = block_sum(q1);
+        __syncthreads();
+        for (int k = tid; k < nz; k += 256) {
+            double s = 0.0;
+            if ((k % sz) == 0) for (int i = 0; i < nx; i += sx) s += b[k * nx + i];
+            rowmean[k] = s / (double)mx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double gsum = 0.0;
+            for (int kk = 0; kk < mz; ++kk) {
+                const double cur = rowmean[kk * sz];
+                if (kk == 0) gsum += rowmean[sz] - cur;
+                else if (kk == mz - 1) gsum += cur - rowmean[(kk - 1) * sz];
+                else gsum += (rowmean[(kk + 1) * sz] - rowmean[(kk - 1) * sz]) / 2;
+            }
+            const double q2 = kap * (gsum / mz), q1m = q1 / ((double)mx * mz);
+            P.nusselt[(size_t)env * 2 + which] = (q1m - q2) / (kap * g.delta_b / g.lz);
+        }
+        __syncthreads();
     }
 }
 

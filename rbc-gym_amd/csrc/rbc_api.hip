@@ -39,7 +39,8 @@ struct rbc3_state;
 
 struct rbc_handle {
     rbc_config cfg;
-    rbc3_state *s3 = nullptr;          // non-null for dim == 3 (rbc3d_host.hpp)
+    rbc3_state *s3 = nullptr;          // streaming path (rbc3d_host.hpp): dim == 3, and dim == 2 grids without an LDS-resident kernel
+    bool stream2d = false;             // dim == 2 on the streaming path (ny = 1): 2D actions, resets and outputs around the 3D stage kernels
     int obs_norm = 0, obs_clip = 0;    // rbc_set_obs_normalization
     float obs_min[5] = {0, 0, 0, 0, 0}, obs_rng[5] = {1, 1, 1, 1, 1}, obs_maxval = 1.0f;
     bool no_pair = false;              // RBC_NO_PAIR=1: unpacked 3D Poisson path (one FFT per slab; A/B and odd nz)
@@ -74,6 +75,9 @@ struct rbc_handle {
 #include "rbc3d_host.hpp"
 
 namespace {
+
+inline bool is3d(const rbc_handle *h) { return h->cfg.dim == 3; }
+inline size_t actions_per_env(const rbc_handle *h) { return is3d(h) ? (size_t)h->cfg.heaters * h->cfg.heaters : (size_t)h->cfg.heaters; }
 
 template <int NX, int NZ, typename T>
 void bind_kernel(rbc_handle *h)
@@ -241,6 +245,8 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
     if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
         return fail(RBC_ERR_INVALID, "ra, pr, dt_solver, dt_control must be positive");
+    if (cfg->dim == 2 && (cfg->nx < 8 || cfg->nz < 8))
+        return fail(RBC_ERR_INVALID, "unsupported 2D grid: at least 8 cells in x and z");
     if (cfg->dim == 2 && (cfg->obs_nx < 1 || cfg->obs_nz < 2 || cfg->nx % cfg->obs_nx || cfg->nz % cfg->obs_nz))
         return fail(RBC_ERR_INVALID, "sensor grid must divide the state grid (and have >= 2 rows)");
     if (cfg->dim == 3 && (cfg->nx < 8 || cfg->ny < 8 || cfg->nz < 8 || !(cfg->ly > 0)))
@@ -254,11 +260,19 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     { const char *e = std::getenv("RBC_NO_TILE"); h->no_tile = e && e[0] == '1'; }
     { const char *e = std::getenv("RBC_NO_PAIR"); h->no_pair = e && e[0] == '1'; }
     { const char *e = std::getenv("RBC_NO_FUSE_Z"); h->no_fuse_z = e && e[0] == '1'; }
+    // 2D: the LDS-resident kernel where it is built for the grid; any other float64 grid runs on the streaming kernels with
+    // ny = 1 (RBC_FORCE_STREAM2D=1 sends every float64 2D handle there: the A/B partner of the resident kernel in the tests)
+    bool force_stream = false;
+    { const char *e = std::getenv("RBC_FORCE_STREAM2D"); force_stream = e && e[0] == '1' && cfg->precision == RBC_PRECISION_F64; }
     if (cfg->dim == 3) { /* streaming kernels, any grid whose horizontal slab fits the LDS FFT */ }
-    else if (!bind_grid(h, cfg->nx, cfg->nz, cfg->precision)) {
-        delete h;
-        return fail(RBC_ERR_INVALID, "unsupported 2D grid: the LDS-resident kernel is built for (nx, nz) in float64: (96,64) (96,48) (96,32) "
-                                     "(64,64) (64,48) (64,32) (128,32); float32: (96,64) (128,64) (64,64) (192,32)");
+    else if (force_stream || !bind_grid(h, cfg->nx, cfg->nz, cfg->precision)) {
+        if (cfg->precision != RBC_PRECISION_F64) {
+            delete h;
+            return fail(RBC_ERR_INVALID, "unsupported 2D grid for precision=float32: the LDS-resident float32 kernel is built for (nx, nz) = (96,64) "
+                                         "(128,64) (64,64) (192,32); other grids run in float64 on the streaming path");
+        }
+        h->stream2d = true;
+        h->cfg.ny = 1; h->cfg.ly = 1.0;
     }
     h->ncell = (size_t)h->nx * h->nz * (cfg->dim == 3 ? cfg->ny : 1);
     h->env_stride = (size_t)(3 * h->nz + 1) * h->nx;
@@ -292,7 +306,7 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     const size_t B = h->B;
-    const size_t nact = (cfg->dim == 3) ? (size_t)cfg->heaters * cfg->heaters : (size_t)cfg->heaters;
+    const size_t nact = actions_per_env(h);
     CREATE_TRY(hipMalloc(&h->d_ra, B * 2 * sizeof(double)));   // (nu, kappa) per env
     CREATE_TRY(hipMalloc(&h->d_actions, B * nact * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->d_mask, B));
@@ -305,8 +319,12 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
         for (size_t e = 0; e < B; ++e) { nk[2 * e] = std::sqrt(cfg->pr / cfg->ra); nk[2 * e + 1] = 1.0 / std::sqrt(cfg->pr * cfg->ra); }
         CREATE_TRY(hipMemcpy(h->d_ra, nk.data(), nk.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (cfg->dim == 3) {
-        CREATE_TRY(hipMalloc(&h->d_state, B * 4 * h->ncell * sizeof(float)));
+    if (cfg->dim == 3 || h->stream2d) {
+        if (h->stream2d) {
+            CREATE_TRY(hipMalloc(&h->d_obs, B * 5 * h->obs_sz * sizeof(float)));
+            CREATE_TRY(hipMalloc(&h->d_state, B * 5 * h->ncell * sizeof(float)));
+            CREATE_TRY(hipMemset(h->d_state, 0, B * 5 * h->ncell * sizeof(float)));
+        } else CREATE_TRY(hipMalloc(&h->d_state, B * 4 * h->ncell * sizeof(float)));
         if (int rc = create3d(h)) { rbc_destroy(h); return rc; }
         h->t.assign(B, 0.0);
         h->step.assign(B, 1);
@@ -419,8 +437,12 @@ int rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->s3) {
         rbc3_state *s = h->s3;
-        hipLaunchKernelGGL(rbc3::k3_random, grid_for((size_t)h->B * s->g.nw, 256), dim3(256), 0, h->stream, s->g, s->st[s->cur],
-                           h->d_seeds, h->d_mask, h->B);
+        if (h->stream2d)
+            hipLaunchKernelGGL(rbc3::k2s_random, grid_for((size_t)h->B * s->g.nc, 256), dim3(256), 0, h->stream, s->g, s->st[s->cur],
+                               h->d_seeds, h->d_mask, h->B);
+        else
+            hipLaunchKernelGGL(rbc3::k3_random, grid_for((size_t)h->B * s->g.nw, 256), dim3(256), 0, h->stream, s->g, s->st[s->cur],
+                               h->d_seeds, h->d_mask, h->B);
         if (int rc = finish_reset3d(h)) return rc;
         mark_reset(h, m);
         return RBC_OK;
@@ -437,7 +459,7 @@ int rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds)
 int rbc_reset_from_arrays3(rbc_handle *h, const uint8_t *mask, const double *b, const double *u, const double *v, const double *w)
 {
     if (int rc = check_handle(h)) return rc;
-    if (!h->s3) return fail(RBC_ERR_INVALID, "rbc_reset_from_arrays3 needs a dim=3 handle");
+    if (!is3d(h)) return fail(RBC_ERR_INVALID, "rbc_reset_from_arrays3 needs a dim=3 handle");
     if (!b || !u || !v || !w) return fail(RBC_ERR_INVALID, "null field array");
     HIP_TRY(hipSetDevice(h->cfg.device));
     std::vector<uint8_t> m;
@@ -462,12 +484,27 @@ int rbc_reset_from_arrays3(rbc_handle *h, const uint8_t *mask, const double *b, 
 int rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask, const double *b, const double *u, const double *w)
 {
     if (int rc = check_handle(h)) return rc;
-    if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_reset_from_arrays3 (b,u,v,w)");
+    if (is3d(h)) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_reset_from_arrays3 (b,u,v,w)");
     if (!b || !u || !w) return fail(RBC_ERR_INVALID, "null field array");
     HIP_TRY(hipSetDevice(h->cfg.device));
     std::vector<uint8_t> m;
     if (int rc = upload_mask(h, mask, m)) return rc;
     const size_t nc = h->ncell, nw = nc + h->nx;
+    if (h->stream2d) {                                  // streaming layout [b | u | v = 0 | w]
+        rbc3_state *s = h->s3;
+        h->stage.assign(s->g.env_stride, 0.0);
+        for (int e = 0; e < h->B; ++e) {
+            if (!m[e]) continue;
+            std::memcpy(h->stage.data(), b + (size_t)e * nc, nc * sizeof(double));
+            std::memcpy(h->stage.data() + nc, u + (size_t)e * nc, nc * sizeof(double));
+            std::memcpy(h->stage.data() + 3 * nc, w + (size_t)e * nw, nw * sizeof(double));
+            HIP_TRY(hipMemcpy(s->st[s->cur] + (size_t)e * s->g.env_stride, h->stage.data(), s->g.env_stride * sizeof(double),
+                              hipMemcpyHostToDevice));
+        }
+        if (int rc = finish_reset3d(h)) return rc;
+        mark_reset(h, m);
+        return RBC_OK;
+    }
     h->stage.resize(h->env_stride);
     for (int e = 0; e < h->B; ++e) {
         if (!m[e]) continue;
@@ -489,7 +526,7 @@ int rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask, const double *b, c
 static void advance_clocks(rbc_handle *h)
 {
     for (int e = 0; e < h->B; ++e) {
-        h->t[e] += h->cfg.dt_control * (h->s3 ? h->cfg.lz * h->cfg.lz : 1.0);   // api:87 (3D: rbc_sim3D_api.jl:89)
+        h->t[e] += h->cfg.dt_control * (is3d(h) ? h->cfg.lz * h->cfg.lz : 1.0);   // api:87 (3D: rbc_sim3D_api.jl:89)
         h->step[e] += 1;                // api:88
     }
 }
@@ -518,7 +555,7 @@ int rbc_step(rbc_handle *h, const float *actions)
     if (int rc = all_initialized(h)) return rc;
     if (!actions) return fail(RBC_ERR_INVALID, "null actions");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    const size_t nact = h->s3 ? (size_t)h->cfg.heaters * h->cfg.heaters : (size_t)h->cfg.heaters;
+    const size_t nact = actions_per_env(h);
     HIP_TRY(hipMemcpyAsync(h->d_actions, actions, (size_t)h->B * nact * sizeof(float), hipMemcpyHostToDevice,
                            h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // `actions` may be pageable: do not return before it is consumed
@@ -533,7 +570,7 @@ int rbc_step(rbc_handle *h, const float *actions)
 
 static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t chan, int nch)
 {
-    const int total = h->s3 ? 4 : 5;       // 3D: b,u,v,w (rbc_sim3D_api.jl:106-121); 2D: b,u,w,pHY',pNHS
+    const int total = is3d(h) ? 4 : 5;       // 3D: b,u,v,w (rbc_sim3D_api.jl:106-121); 2D: b,u,w,pHY',pNHS
     if (!out) return fail(RBC_ERR_INVALID, "null output");
     if (nch < 1 || nch > total) return fail(RBC_ERR_INVALID, "nch out of range");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -546,7 +583,7 @@ static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t cha
 int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip)
 {
     if (int rc = check_handle(h)) return rc;
-    if (h->s3) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: the 3D observation is the raw state; normalise on the host");
+    if (is3d(h)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: the 3D observation is the raw state; normalise on the host");
     if (nch < 0 || nch > 5) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: nch must be in [0, 5]");
     if (nch > 0 && (!min_vals || !max_vals)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: NULL bounds");
     for (int c = 0; c < nch; ++c) {
@@ -563,7 +600,7 @@ int rbc_get_cell_distances(rbc_handle *h, double height, double *out)
 {
     if (int rc = check_handle(h)) return rc;
     if (int rc = all_initialized(h)) return rc;
-    if (h->s3) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances: 2D envs only (the reference's wrapper reads a 2D mid-line)");
+    if (is3d(h)) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances: 2D envs only (the reference's wrapper reads a 2D mid-line)");
     if (!h->cfg.write_state) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances needs write_state=1 (it reads the float32 state)");
     if (!out) return fail(RBC_ERR_INVALID, "null output");
     if (h->nx > 256) return fail(RBC_ERR_INVALID, "rbc_get_cell_distances: nx <= 256");
@@ -615,7 +652,7 @@ int rbc_get_obs(rbc_handle *h, float *out, int nch)
 {
     if (int rc = check_handle(h)) return rc;
     if (int rc = all_initialized(h)) return rc;
-    if (h->s3) return copy_channels(h, out, h->d_state, h->ncell, nch);     // 3D: the observation IS the state (rbc3D.py:229-232)
+    if (is3d(h)) return copy_channels(h, out, h->d_state, h->ncell, nch);     // 3D: the observation IS the state (rbc3D.py:229-232)
     return copy_channels(h, out, h->d_obs, h->obs_sz, nch);
 }
 
@@ -623,14 +660,14 @@ int rbc_get_state(rbc_handle *h, float *out, int nch)
 {
     if (int rc = check_handle(h)) return rc;
     if (int rc = all_initialized(h)) return rc;
-    if (!h->s3 && !h->cfg.write_state) return fail(RBC_ERR_INVALID, "handle was created with write_state=0");
+    if (!is3d(h) && !h->cfg.write_state) return fail(RBC_ERR_INVALID, "handle was created with write_state=0");
     return copy_channels(h, out, h->d_state, h->ncell, nch);
 }
 
 int rbc_get_fields3(rbc_handle *h, double *b, double *u, double *v, double *w)
 {
     if (int rc = check_handle(h)) return rc;
-    if (!h->s3) return fail(RBC_ERR_INVALID, "rbc_get_fields3 needs a dim=3 handle");
+    if (!is3d(h)) return fail(RBC_ERR_INVALID, "rbc_get_fields3 needs a dim=3 handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     rbc3_state *s = h->s3;
@@ -646,9 +683,18 @@ int rbc_get_fields3(rbc_handle *h, double *b, double *u, double *v, double *w)
 int rbc_get_fields(rbc_handle *h, double *b, double *u, double *w)
 {
     if (int rc = check_handle(h)) return rc;
-    if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_get_fields3");
+    if (is3d(h)) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_get_fields3");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->stream2d) {
+        rbc3_state *s = h->s3;
+        const size_t nc = s->g.nc, nw = s->g.nw, pitch = s->g.env_stride * sizeof(double);
+        const double *base = s->st[s->cur];
+        if (b) HIP_TRY(hipMemcpy2D(b, nc * sizeof(double), base, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+        if (u) HIP_TRY(hipMemcpy2D(u, nc * sizeof(double), base + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
+        if (w) HIP_TRY(hipMemcpy2D(w, nw * sizeof(double), base + 3 * nc, pitch, nw * sizeof(double), h->B, hipMemcpyDeviceToHost));
+        return RBC_OK;
+    }
     const size_t nc = h->ncell, nw = nc + h->nx, pitch = h->env_stride * sizeof(double);
     if (b) HIP_TRY(hipMemcpy2D(b, nc * sizeof(double), h->d_fields, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
     if (u) HIP_TRY(hipMemcpy2D(u, nc * sizeof(double), h->d_fields + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
@@ -665,7 +711,7 @@ int rbc_get_nusselt(rbc_handle *h, double *nu_state, double *nu_obs)
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_nu, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int e = 0; e < h->B; ++e) {
-        if (h->s3) {                         // 3D has one Nusselt number (rbc_sim3D_api.jl:134): d_nu is [B]
+        if (is3d(h)) {                       // 3D has one Nusselt number (rbc_sim3D_api.jl:134): d_nu is [B]
             if (nu_state) nu_state[e] = tmp[e];
             if (nu_obs) nu_obs[e] = tmp[e];
             continue;
@@ -785,13 +831,13 @@ double rbc_algorithmic_bytes_per_env_step(rbc_handle *h)
 {
     if (!h) return 0.0;
     // B_sub = 10 * F * C * s (F prognostic fields: 3 in 2D, 4 in 3D; C cells; s = 8 bytes, 4 for the float32 variant) per RK3 substep
-    return (double)h->nsub * 10.0 * (h->s3 ? 4.0 : 3.0) * (double)h->ncell * (h->cfg.precision == RBC_PRECISION_F32 ? 4.0 : 8.0);
+    return (double)h->nsub * 10.0 * (is3d(h) ? 4.0 : 3.0) * (double)h->ncell * (h->cfg.precision == RBC_PRECISION_F32 ? 4.0 : 8.0);
 }
 
 int rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, double *gv, double *gw, double *gb)
 {
     if (int rc = check_handle(h)) return rc;
-    if (!h->s3) return fail(RBC_ERR_INVALID, "needs a dim=3 handle");
+    if (!is3d(h)) return fail(RBC_ERR_INVALID, "needs a dim=3 handle");
     if (!actions || !gu || !gv || !gw || !gb) return fail(RBC_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     rbc3_state *s = h->s3;
@@ -820,8 +866,31 @@ int rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, doubl
 int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw)
 {
     if (int rc = check_handle(h)) return rc;
-    if (h->s3) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_debug_tendencies3");
+    if (is3d(h)) return fail(RBC_ERR_INVALID, "dim=3 handles take rbc_debug_tendencies3");
     if (!actions || !gb || !gu || !gw) return fail(RBC_ERR_INVALID, "null argument");
+    if (h->stream2d) {                     // the cell-per-thread tendency kernels on the ny = 1 state
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        rbc3_state *s = h->s3;
+        const rbc3::Geo3 &g = s->g;
+        const int B = h->B;
+        const size_t nc = g.nc;
+        if (!s->dbg) HIP_TRY(hipMalloc(&s->dbg, (size_t)B * 4 * nc * sizeof(double)));
+        HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)B * g.heaters * sizeof(float), hipMemcpyHostToDevice));
+        wall3d(h, h->d_actions, 0);
+        double *cur = s->st[s->cur];
+        hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
+        const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
+        hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+        hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+        hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const size_t pitch = 4 * nc * sizeof(double);
+        HIP_TRY(hipMemcpy2D(gb, nc * sizeof(double), s->dbg + 3 * nc, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(gu, nc * sizeof(double), s->dbg, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(gw, nc * sizeof(double), s->dbg + 2 * nc, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
+        return RBC_OK;
+    }
     if (h->lanes != 1) return fail(RBC_ERR_INVALID, "rbc_debug_tendencies: not available on the packed float32 kernel (RBC_F32_SCALAR=1 selects the scalar one)");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t nc = h->ncell;
@@ -857,7 +926,7 @@ int rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt)
     if (!actions || nsub < 1 || !(dt > 0)) return fail(RBC_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->s3) {
-        HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * h->cfg.heaters * h->cfg.heaters * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * actions_per_env(h) * sizeof(float), hipMemcpyHostToDevice));
         if (int rc = step3d(h, h->d_actions, nsub, dt, dt, false)) return rc;
         HIP_TRY(hipStreamSynchronize(h->stream));
         return RBC_OK;

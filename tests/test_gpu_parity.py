@@ -314,9 +314,12 @@ def test_heater_profile_with_active_blend_zones_matches_oracle(native, oracle):
 
 
 def test_unsupported_grids_fail_loudly(native):
-    for nx, nz in ((100, 64), (96, 40), (256, 64), (128, 64)):          # 128x64 float64 does not fit a CU's LDS (float32 does)
-        with pytest.raises(native.RbcError):
-            native.NativeSim(batch=1, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8)
+    """float64 grids without an LDS-resident kernel run on the streaming path (tests/test_gpu_stream2d.py); what is left to
+    refuse: grids below 8 cells, and float32 (resident kernels only) on a grid it is not built for."""
+    for nx, nz, prec in ((4, 64, 0), (96, 4, 0), (100, 64, 1), (96, 40, 1), (256, 64, 1)):
+        with pytest.raises(native.RbcError) as e:
+            native.NativeSim(batch=1, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=4, precision=prec)
+        assert "unsupported 2D grid" in str(e.value)
 
 
 # ---------------------------------------------------------------------------------------------

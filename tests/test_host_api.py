@@ -59,7 +59,7 @@ def test_default_config_is_the_registry_default(native):
 
 def test_invalid_configs_are_rejected_before_touching_the_device(native):
     lib = native.load_library()
-    for field, value, frag in (("dim", 4, "dim must be"), ("nx", 192, "unsupported 2D grid"), ("precision", 7, "precision"), ("batch", 0, "batch"),
+    for field, value, frag in (("dim", 4, "dim must be"), ("nx", 4, "unsupported 2D grid"), ("precision", 7, "precision"), ("batch", 0, "batch"),
                                ("heaters", 0, "heaters"), ("obs_nx", 5, "sensor"), ("abi_version", 99, "abi_version")):
         cfg = native.default_config()
         setattr(cfg, field, value)
