@@ -50,7 +50,9 @@ typedef struct rbc_config {
     int32_t abi_version;     /* = RBC_ABI_VERSION                                            */
     int32_t dim;             /* 2, or 3 (rbc_sim3D_api.jl: grid (nx,ny,nz), L (lx,ly,lz), heaters x heaters
                                 actions, dt_* in free-fall units scaled by t_ff = lz^2, 4 channels b,u,v,w) */
-    int32_t nx, ny, nz;      /* grid = state_shape[::-1]  (96, 1, 64)                        */
+    int32_t nx, ny, nz;      /* grid = state_shape[::-1]  (96, 1, 64).  dim=2, float64: any nx, nz >= 8 (the reference
+                                takes any grid: rbc_sim2D_api.jl:17-25); the LDS-resident kernel where it is built for
+                                the grid, the streaming kernels with ny = 1 otherwise          */
     double  lx, ly, lz;      /* L = [2*pi, 2]                                   (api:28)     */
     double  ra;              /* default Rayleigh number for every env            (api:17)     */
     double  pr;              /* 0.7                                             (api:35)     */
@@ -159,7 +161,9 @@ void *rbc_dev_obs(rbc_handle *h);
 void *rbc_dev_state(rbc_handle *h);
 void *rbc_dev_nusselt(rbc_handle *h);
 void *rbc_dev_flags(rbc_handle *h);
-void *rbc_dev_fields(rbc_handle *h);   /* float64 [B][ b(nz*nx) | u(nz*nx) | w((nz+1)*nx) ] */
+void *rbc_dev_fields(rbc_handle *h);   /* float64 [B][ b(nz*nx) | u(nz*nx) | w((nz+1)*nx) ]; 2D handles on the streaming path
+                                          (grids without an LDS-resident kernel): [B][ b | u | v = 0 | w ] of the buffer that
+                                          currently holds the state (it alternates between two with every RK3 stage) */
 
 /* measurement support for bench.py: HIP events are recorded on the handle's stream around
    every step-kernel launch of rbc_step / rbc_step_dev (up to max_launches launches between

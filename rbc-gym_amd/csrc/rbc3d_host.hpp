@@ -71,6 +71,7 @@ int create3d(rbc_handle *h)
     factor2(ny, s->plan.ny1, s->plan.ny2);
     s->fft_lds = ((size_t)2 * c.nx * ny + c.nx + ny) * sizeof(double2);
     { const int items = 8 * (c.nx > ny ? c.nx : ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
+    if (h->stream2d) s->fft_threads = c.nx >= 256 ? 256 : (c.nx + 63) / 64 * 64;      // a "slab" is one row: one work item per point
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
     const size_t B = h->B;
     for (int q = 0; q < 2; ++q) {
@@ -221,12 +222,14 @@ int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, doub
             } else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
                 const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
                 hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
-                hipLaunchKernelGGL(rbc3::k3_tend_march<1>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
+                if (!h->stream2d)                              // ny = 1: v and its tendency are identically zero in both state buffers
+                    hipLaunchKernelGGL(rbc3::k3_tend_march<1>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
                 hipLaunchKernelGGL(rbc3::k3_tend_march<2>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
                 hipLaunchKernelGGL(rbc3::k3_tend_march<3>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
             } else {
                 hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-                hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                if (!h->stream2d)
+                    hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
                 hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
                 hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
             }
@@ -279,6 +282,8 @@ int finish_reset3d(rbc_handle *h)
 {
     rbc3_state *s = h->s3;
     wall3d(h, nullptr, 1);
+    if (h->stream2d)
+        hipLaunchKernelGGL(rbc3::k2s_clear_v, grid_for((size_t)h->B * s->g.nc, 256), dim3(256), 0, h->stream, s->g, s->st[0], s->st[1], h->d_mask, h->B);
     if (int rc = project3d(h, s->st[s->cur], 1.0, h->d_mask)) return rc;
     if (int rc = output3d(h, h->d_mask)) return rc;
     HIP3(hipStreamSynchronize(h->stream));

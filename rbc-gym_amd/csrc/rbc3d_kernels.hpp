@@ -1364,6 +1364,18 @@ __global__ void k2s_random(Geo3 g, double *st, const uint64_t *seeds, const uint
     sb[c0] = fmin(fmax(val, g.min_b), g.min_b + g.delta_b);
 }
 
+// v of the envs being reset, in BOTH state buffers: the v tendency kernel is not launched in streaming-2D mode (v == 0), so a
+// NaN that a blown-up env left in the other buffer would otherwise survive the reset
+__global__ void k2s_clear_v(Geo3 g, double *st0, double *st1, const uint8_t *mask, int B)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= g.nc * B) return;
+    const int env = cell / g.nc, c0 = cell - env * g.nc;
+    if (mask && !mask[env]) return;
+    const size_t o = (size_t)env * g.env_stride + 2 * (size_t)g.nc + c0;
+    st0[o] = 0.0; st1[o] = 0.0;
+}
+
 struct Out2D {
     float *obs, *state32;       // [B][5][obs_nz][obs_nx], [B][5][nz][nx]
     double *nusselt;            // [B][2]

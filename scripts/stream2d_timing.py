@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the streaming 2D path (2D grids without an LDS-resident kernel) and, on the default grid, against the resident kernel.
-usage: python scripts/stream2d_timing.py [B] [steps]"""
+usage: python scripts/stream2d_timing.py [B] [steps] [nx nz]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rbc-gym_amd"))
@@ -26,6 +26,10 @@ def run(label, **kw):
     sim.close()
 
 
+if len(sys.argv) > 4:            # one grid only (profiling): B steps nx nz
+    nx, nz = int(sys.argv[3]), int(sys.argv[4])
+    run(f"{nx}x{nz} streaming", nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8)
+    sys.exit(0)
 run("96x64 resident")
 os.environ["RBC_FORCE_STREAM2D"] = "1"
 run("96x64 streaming")

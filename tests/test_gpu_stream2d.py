@@ -143,6 +143,14 @@ def test_streaming_and_resident_kernels_agree_on_the_default_grid(native, oracle
     assert np.array_equal(f_before[0][0], f_after[0][0]) and np.array_equal(f_before[1][2], f_after[1][2])
     assert not strm.step(np.zeros((B, 12), np.float32))
     assert list(strm.get_flags()) == [0, 1, 0]
+    # a blown-up env comes back after a masked reset (the NaN must not survive in either state buffer)
+    good = [np.stack([ic[q] for ic in ics]) for q in (1, 2, 3)]
+    strm.reset_from_arrays(*good, mask=[0, 1, 0])
+    res.reset_from_arrays(*good, mask=[0, 1, 0])
+    act = rng.uniform(-1, 1, (B, 12)).astype(np.float32)
+    assert strm.step(act) and res.step(act)
+    for x, y in zip(res.get_fields(), strm.get_fields()):
+        assert np.isfinite(y).all() and rel_l2(y[1], x[1]) < 1e-9
     with pytest.raises(native.RbcError):
         native.NativeSim(batch=1, nx=128, nz=64, obs_nx=64, obs_nz=8, precision=1).step(np.zeros((1, 12), np.float32))   # float32 128x64 is resident; not initialised
     with pytest.raises(native.RbcError) as e:
