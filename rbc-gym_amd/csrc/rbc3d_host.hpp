@@ -23,7 +23,17 @@ struct rbc3_state {
     // one captured HIP graph per ping-pong parity of the standard env-step (39 stages is odd, so the
     // starting buffer alternates): ~350 launches replayed as one graph launch
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    // env groups: the batch is cut into `groups` contiguous ranges and every range runs its own chain of stage kernels on its
+    // own stream (envs are independent), so that one group's latency-bound phases (single-round FFT launches, kernel tails)
+    // overlap another group's tendency kernels.  1 = the whole batch on the handle's stream.
+    int groups = 1;
+    std::vector<hipStream_t> gstream;
+    std::vector<hipEvent_t> gdone;
+    hipEvent_t gstart = nullptr;
 };
+
+// a contiguous range of envs and the stream its launches go to
+struct rbc3_grp { int e0, B; hipStream_t st; };
 
 namespace {
 
@@ -108,6 +118,22 @@ int create3d(rbc_handle *h)
         HIP3(hipMalloc(&s->tab, tab.size() * sizeof(double)));
         HIP3(hipMemcpy(s->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    {   // RBC_3D_GROUPS=n overrides the default (4 groups of >= 4 envs for 3D handles; streaming-2D batches are large: 1)
+        int want = h->stream2d ? 1 : 4;
+        if (const char *e = std::getenv("RBC_3D_GROUPS")) want = std::atoi(e);
+        if (want > 16) want = 16;
+        while (want > 1 && h->B / want < 4) --want;
+        s->groups = want < 1 ? 1 : want;
+        if (s->groups > 1 && !std::getenv("RBC_USE_GRAPH")) h->no_graph = false;     // several chains: replay them as one captured graph
+        if (s->groups > 1) {
+            s->gstream.resize(s->groups); s->gdone.resize(s->groups);
+            for (int q = 0; q < s->groups; ++q) {
+                HIP3(hipStreamCreateWithFlags(&s->gstream[q], hipStreamNonBlocking));
+                HIP3(hipEventCreateWithFlags(&s->gdone[q], hipEventDisableTiming));
+            }
+            HIP3(hipEventCreateWithFlags(&s->gstart, hipEventDisableTiming));
+        }
+    }
     HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
     HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_ifft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
     HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
@@ -115,12 +141,22 @@ int create3d(rbc_handle *h)
     return RBC_OK;
 }
 
+void drop_graphs3d(rbc_handle *h)
+{
+    if (!h->s3) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &g : h->s3->gexec)
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
+
 void destroy3d(rbc_handle *h)
 {
     rbc3_state *s = h->s3;
     if (!s) return;
-    for (auto &g : s->gexec)
-        if (g) (void)hipGraphExecDestroy(g);
+    drop_graphs3d(h);
+    for (hipStream_t q : s->gstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (hipEvent_t e : s->gdone) if (e) (void)hipEventDestroy(e);
+    if (s->gstart) (void)hipEventDestroy(s->gstart);
     void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -130,114 +166,177 @@ void destroy3d(rbc_handle *h)
 
 inline dim3 grid_for(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-// exact projection of state buffer `buf` with stage step dts (mask: device pointer or null)
-int project3d(rbc_handle *h, double *buf, double dts, const uint8_t *mask)
+inline rbc3_grp whole_batch(const rbc_handle *h) { return rbc3_grp{0, h->B, h->stream}; }
+
+// exact projection of state buffer `which` (0/1) of the group's envs with stage step dts (mask: device pointer [B] or null)
+int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask)
 {
     rbc3_state *s = h->s3;
     const rbc3::Geo3 &g = s->g;
-    const int B = h->B;
+    const int B = q.B;
+    const size_t pln = (size_t)g.nx * g.ny;
+    double *buf = s->st[which] + (size_t)q.e0 * g.env_stride;
+    double *phi = s->phi + (size_t)q.e0 * g.nc;
+    const uint8_t *mk = mask ? mask + q.e0 : nullptr;
     if (g.nz % 2 == 0 && !h->no_pair) {      // mirror slabs packed as one complex transform, z solve on the packed spectrum
-        const dim3 gm_ = grid_for((size_t)B * g.nx * g.ny, 128);
-        hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
-        if (g.nz == 32 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<16>, gm_, dim3(128), 0, h->stream, g, s->spec, s->tab, B);
-        else if (g.nz == 16 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<8>, gm_, dim3(128), 0, h->stream, g, s->spec, s->tab, B);
+        double2 *spec = s->spec + (size_t)q.e0 * (g.nz / 2) * pln, *jct = s->jct + (size_t)q.e0 * pln;
+        const dim3 gm_ = grid_for((size_t)B * pln, 128);
+        hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, buf, spec, dts);
+        if (g.nz == 32 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<16>, gm_, dim3(128), 0, q.st, g, spec, s->tab, B);
+        else if (g.nz == 16 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<8>, gm_, dim3(128), 0, q.st, g, spec, s->tab, B);
         else {
-            hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
-            hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, h->stream, g, s->spec, s->jct, s->tab, B);
+            hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, q.st, g, spec, jct, s->tab, B);
+            hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, q.st, g, spec, jct, s->tab, B);
         }
-        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi, buf, dts, mask);
-        hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - g.nx * g.ny), 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
+        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
+        hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
         HIP3(hipGetLastError());
         return RBC_OK;
-    } else {
-        hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, buf, s->spec, dts);
-        hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, s->spec, s->tab, B);
-        hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(s->fft_threads), s->fft_lds, h->stream, g, s->plan, s->spec, s->phi);
     }
-    hipLaunchKernelGGL(rbc3::k3_correct, grid_for((size_t)B * g.nc, 256), dim3(256), 0, h->stream, g, buf, s->phi, dts, B, mask);
+    double2 *spec = s->spec + (size_t)q.e0 * g.nz * pln;
+    hipLaunchKernelGGL(rbc3::k3_rhs_fft, dim3(B * g.nz), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, buf, spec, dts);
+    hipLaunchKernelGGL(rbc3::k3_thomas, grid_for((size_t)B * pln, 128), dim3(128), 0, q.st, g, spec, s->tab, B);
+    hipLaunchKernelGGL(rbc3::k3_ifft, dim3(B * g.nz), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi);
+    hipLaunchKernelGGL(rbc3::k3_correct, grid_for((size_t)B * g.nc, 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
     HIP3(hipGetLastError());
     return RBC_OK;
 }
 
-int output3d(rbc_handle *h, const uint8_t *mask)
+// outputs of the group's envs from state buffer `which`
+int output3d(rbc_handle *h, const rbc3_grp &q, int which, const uint8_t *mask)
 {
     rbc3_state *s = h->s3;
+    const rbc3::Geo3 &g = s->g;
+    const double *st = s->st[which] + (size_t)q.e0 * g.env_stride;
+    const uint8_t *mk = mask ? mask + q.e0 : nullptr;
     if (h->stream2d) {
         rbc3::Out2D o{};
-        o.obs = h->d_obs; o.state32 = h->d_state; o.nusselt = h->d_nu; o.flags = h->d_flags;
+        o.obs = h->d_obs + (size_t)q.e0 * 5 * h->obs_sz; o.state32 = h->d_state + (size_t)q.e0 * 5 * g.nc;
+        o.nusselt = h->d_nu + (size_t)q.e0 * 2; o.flags = h->d_flags + q.e0;
         o.obs_nx = h->cfg.obs_nx; o.obs_nz = h->cfg.obs_nz; o.write_state = h->cfg.write_state;
         o.obs_norm = h->obs_norm; o.obs_clip = h->obs_clip; o.obs_maxval = h->obs_maxval;
         for (int c = 0; c < 5; ++c) { o.obs_min[c] = h->obs_min[c]; o.obs_rng[c] = h->obs_rng[c]; }
-        hipLaunchKernelGGL(rbc3::k2s_output, dim3(h->B), dim3(256), (2 * (size_t)s->g.nz + 256) * sizeof(double), h->stream, s->g, s->st[s->cur], s->phi,
-                           h->d_ra, o, mask);
+        hipLaunchKernelGGL(rbc3::k2s_output, dim3(q.B), dim3(256), (2 * (size_t)g.nz + 256) * sizeof(double), q.st, g, st, s->phi + (size_t)q.e0 * g.nc,
+                           h->d_ra + (size_t)q.e0 * 2, o, mk);
         HIP3(hipGetLastError());
         return RBC_OK;
     }
-    hipLaunchKernelGGL(rbc3::k3_output, dim3(h->B * rbc3::OUT_SPLIT), dim3(256), 0, h->stream, s->g, s->st[s->cur], h->d_ra, h->d_state, h->d_nu, h->d_flags, mask,
-                       s->out_part, s->out_arrive);
+    hipLaunchKernelGGL(rbc3::k3_output, dim3(q.B * rbc3::OUT_SPLIT), dim3(256), 0, q.st, g, st, h->d_ra + (size_t)q.e0 * 2, h->d_state + (size_t)q.e0 * 4 * g.nc,
+                       h->d_nu + q.e0, h->d_flags + q.e0, mk, s->out_part + (size_t)q.e0 * 2 * rbc3::OUT_SPLIT, s->out_arrive + q.e0);
     HIP3(hipGetLastError());
     return RBC_OK;
 }
 
-// bottom-plate table of every env from the raw actions: preprocess_action (3D) / collate_actions_colin per column (streaming 2D)
-void wall3d(rbc_handle *h, const float *actions_dev, int zero)
-{
-    rbc3_state *s = h->s3;
-    if (h->stream2d)
-        hipLaunchKernelGGL(rbc3::k2s_wall, grid_for((size_t)h->B * s->g.nx, 128), dim3(128), 0, h->stream, s->g, actions_dev, s->actT, zero, h->B);
-    else
-        hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(h->B), dim3(64), 0, h->stream, s->g, actions_dev, s->actT, zero);
-}
-
-// one stage list for `nsub` substeps (the last of size dt_last); actions already on the device
-int advance3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last)
+// bottom-plate table of the group's envs from the raw actions: preprocess_action (3D) / collate_actions_colin per column (streaming 2D)
+void wall3d(rbc_handle *h, const rbc3_grp &q, const float *actions_dev, int zero)
 {
     rbc3_state *s = h->s3;
     const rbc3::Geo3 &g = s->g;
-    const int B = h->B;
-    wall3d(h, actions_dev, 0);
+    if (h->stream2d)
+        hipLaunchKernelGGL(rbc3::k2s_wall, grid_for((size_t)q.B * g.nx, 128), dim3(128), 0, q.st, g, actions_dev ? actions_dev + (size_t)q.e0 * g.heaters : nullptr,
+                           s->actT + (size_t)q.e0 * g.nx, zero, q.B);
+    else
+        hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(q.B), dim3(64), 0, q.st, g, actions_dev ? actions_dev + (size_t)q.e0 * g.heaters * g.heaters : nullptr,
+                           s->actT + (size_t)q.e0 * g.heaters * g.heaters, zero);
+}
+
+// the stage list of `nsub` substeps (the last of size dt_last) for one group of envs, starting from state buffer `which`;
+// actions already on the device.  Returns the buffer that holds the state afterwards through *which_out.
+int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_dev, int nsub, double dt, double dt_last, int *which_out)
+{
+    rbc3_state *s = h->s3;
+    const rbc3::Geo3 &g = s->g;
+    const int B = q.B;
+    wall3d(h, q, actions_dev, 0);
     const double *gam = s->gam, *zet = s->zet;
     const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
+    const size_t eo = (size_t)q.e0 * g.env_stride;
+    double *gm = s->gm + eo, *phy = s->phy + (size_t)q.e0 * g.nc;
+    const double *actT = s->actT + (size_t)q.e0 * (g.wall_nx ? (size_t)g.wall_nx : (size_t)g.heaters * g.heaters);
+    const double *ra = h->d_ra + (size_t)q.e0 * 2;
+    auto tiles_fit = [&](int ty, int kt, int maxt) {
+        const int thr = g.nx * ty;
+        return !h->no_tile && g.nz % kt == 0 && g.ny % ty == 0 && thr <= maxt && thr % 64 == 0 && g.nx <= rbc3::NXP3 &&
+               (ty + 6) * g.nx <= 2 * thr;
+    };
+    // LDS-tiled tendency kernels (planes staged once per level; first half of the grid: (u, v), second half: (w, b)).  Tile shapes
+    // (rows of y x levels of z): with several env groups in flight a launch only has to fill its share of the chip, and tall
+    // tiles win (fewer chunk prologues: the z windows of a column are loaded once per chunk); a single chain needs the workgroup
+    // count of 16 x 4.  RBC_TILE_SHAPE=16x16|16x8|16x4|8x8 forces one (A/B runs).
+    const char *tshape = std::getenv("RBC_TILE_SHAPE");
+    auto want = [&](const char *name, bool dflt) { return tshape ? std::strcmp(tshape, name) == 0 : dflt; };
+    int shape = 0;
+    if (want("16x16", s->groups > 1) && tiles_fit(16, 16, 768)) shape = 1;
+    else if (want("16x8", s->groups > 1) && tiles_fit(16, 8, 768)) shape = 2;
+    else if (want("16x4", true) && tiles_fit(16, 4, 768)) shape = 3;
+    else if (want("8x8", true) && tiles_fit(8, 8, 512)) shape = 4;
     for (int n = 0; n < nsub; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;
         for (int ph = 0; ph < 3; ++ph) {
-            double *cur = s->st[s->cur], *nxt = s->st[s->cur ^ 1];
-            auto tiles_fit = [&](int ty, int kt, int maxt) {
-                const int thr = g.nx * ty;
-                return !h->no_tile && g.nz % kt == 0 && g.ny % ty == 0 && thr <= maxt && thr % 64 == 0 && g.nx <= rbc3::NXP3 &&
-                       (ty + 6) * g.nx <= 2 * thr;
-            };
+            double *cur = s->st[which] + eo, *nxt = s->st[which ^ 1] + eo;
             const int store_g = (ph != 2);                     // the last stage's tendencies are never read again (zeta^1 = 0)
-            const bool tiled = tiles_fit(16, 4, 768) || tiles_fit(8, 8, 512);
-            if (!tiled)                                        // the fallback kernels use the hydrostatic split (pHY' column scan)
-                hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
-            if (tiles_fit(16, 4, 768)) {                       // LDS-tiled kernels: planes staged once per level
-                const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / 16) * (g.nz / 4))), bt(g.nx * 16);      // first half: (u, v), second half: (w, b)
-                const size_t pb = (size_t)(16 + 6) * rbc3::NXP3 * sizeof(double);
-                hipLaunchKernelGGL((rbc3::k3_tile_all<16, 4, 2, 768, 3>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
-            } else if (tiles_fit(8, 8, 512)) {
-                const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / 8) * (g.nz / 8))), bt(g.nx * 8);
-                const size_t pb = (size_t)(8 + 6) * rbc3::NXP3 * sizeof(double);
-                hipLaunchKernelGGL((rbc3::k3_tile_all<8, 8, 2, 512, 2>), gt, bt, 3 * pb, h->stream, g, cur, nxt, s->gm, s->actT, h->d_ra, d, gam[ph], zet[ph], store_g);
-            } else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
-                const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
-                hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
-                if (!h->stream2d)                              // ny = 1: v and its tendency are identically zero in both state buffers
-                    hipLaunchKernelGGL(rbc3::k3_tend_march<1>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
-                hipLaunchKernelGGL(rbc3::k3_tend_march<2>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
-                hipLaunchKernelGGL(rbc3::k3_tend_march<3>, gm_, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B);
-            } else {
-                hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-                if (!h->stream2d)
-                    hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-                hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
-                hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, nxt, s->gm, s->phy, s->actT, h->d_ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            if (!shape)                                        // the fallback kernels use the hydrostatic split (pHY' column scan)
+                hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, q.st, g, cur, phy, B);
+#define RBC_TILE_LAUNCH(TY, KT, THR, WAVES)                                                                                              \
+            {                                                                                                                            \
+                const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
+                const size_t pb = (size_t)(TY + 6) * rbc3::NXP3 * sizeof(double);                                                        \
+                hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
             }
-            if (int rc = project3d(h, nxt, (gam[ph] + zet[ph]) * d, nullptr)) return rc;
-            s->cur ^= 1;
+            if (shape == 1) RBC_TILE_LAUNCH(16, 16, 768, 3)
+            else if (shape == 2) RBC_TILE_LAUNCH(16, 8, 768, 3)
+            else if (shape == 3) RBC_TILE_LAUNCH(16, 4, 768, 3)
+            else if (shape == 4) RBC_TILE_LAUNCH(8, 8, 512, 2)
+#undef RBC_TILE_LAUNCH
+            else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
+                const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
+                hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B);
+                if (!h->stream2d)                              // ny = 1: v and its tendency are identically zero in both state buffers
+                    hipLaunchKernelGGL(rbc3::k3_tend_march<1>, gm_, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B);
+                hipLaunchKernelGGL(rbc3::k3_tend_march<2>, gm_, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B);
+                hipLaunchKernelGGL(rbc3::k3_tend_march<3>, gm_, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B);
+            } else {
+                hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                if (!h->stream2d)
+                    hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+                hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
+            }
+            if (int rc = project3d(h, q, which ^ 1, (gam[ph] + zet[ph]) * d, nullptr)) return rc;
+            which ^= 1;
         }
     }
     HIP3(hipGetLastError());
+    *which_out = which;
+    return RBC_OK;
+}
+
+// advance + outputs for the whole batch: every env group's chain on its own stream, forked from and joined back into the
+// handle's stream (the same calls capture into a graph)
+int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last)
+{
+    rbc3_state *s = h->s3;
+    int which = s->cur;
+    if (s->groups <= 1) {
+        const rbc3_grp q = whole_batch(h);
+        if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
+        if (int rc = output3d(h, q, which, nullptr)) return rc;
+        s->cur = which;
+        return RBC_OK;
+    }
+    HIP3(hipEventRecord(s->gstart, h->stream));
+    const int per = (h->B + s->groups - 1) / s->groups;
+    for (int gi = 0; gi < s->groups; ++gi) {
+        const int e0 = gi * per, Bg = (e0 + per <= h->B) ? per : h->B - e0;
+        if (Bg <= 0) continue;
+        const rbc3_grp q{e0, Bg, s->gstream[gi]};
+        HIP3(hipStreamWaitEvent(q.st, s->gstart, 0));
+        if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
+        if (int rc = output3d(h, q, which, nullptr)) return rc;
+        HIP3(hipEventRecord(s->gdone[gi], q.st));
+        HIP3(hipStreamWaitEvent(h->stream, s->gdone[gi], 0));
+    }
+    s->cur = which;
     return RBC_OK;
 }
 
@@ -255,8 +354,7 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
         if (!s->gexec[par]) {
             hipGraph_t graph = nullptr;
             HIP3(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-            int rc = advance3d(h, h->d_actions, nsub, dt, dt_last);
-            if (!rc) rc = output3d(h, nullptr);
+            int rc = run_step3d(h, h->d_actions, nsub, dt, dt_last);
             hipError_t e = hipStreamEndCapture(h->stream, &graph);
             s->cur = par;                               // capture executed nothing: undo the host-side flips
             if (rc) return rc;
@@ -267,8 +365,7 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
         HIP3(hipGraphLaunch(s->gexec[par], h->stream));
         s->cur = par ^ ((3 * nsub) & 1);
     } else {
-        if (int rc = advance3d(h, actions_dev, nsub, dt, dt_last)) return rc;
-        if (int rc = output3d(h, nullptr)) return rc;
+        if (int rc = run_step3d(h, actions_dev, nsub, dt, dt_last)) return rc;
     }
     if (rec) {
         HIP3(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
@@ -281,11 +378,12 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
 int finish_reset3d(rbc_handle *h)
 {
     rbc3_state *s = h->s3;
-    wall3d(h, nullptr, 1);
+    const rbc3_grp q = whole_batch(h);
+    wall3d(h, q, nullptr, 1);
     if (h->stream2d)
         hipLaunchKernelGGL(rbc3::k2s_clear_v, grid_for((size_t)h->B * s->g.nc, 256), dim3(256), 0, h->stream, s->g, s->st[0], s->st[1], h->d_mask, h->B);
-    if (int rc = project3d(h, s->st[s->cur], 1.0, h->d_mask)) return rc;
-    if (int rc = output3d(h, h->d_mask)) return rc;
+    if (int rc = project3d(h, q, s->cur, 1.0, h->d_mask)) return rc;
+    if (int rc = output3d(h, q, s->cur, h->d_mask)) return rc;
     HIP3(hipStreamSynchronize(h->stream));
     return RBC_OK;
 }

@@ -593,6 +593,7 @@ int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const doubl
     }
     for (int c = 0; c < nch; ++c) { h->obs_min[c] = (float)min_vals[c]; h->obs_rng[c] = (float)(max_vals[c] - min_vals[c]); }
     h->obs_norm = nch; h->obs_clip = clip ? 1 : 0; h->obs_maxval = (float)maxval;
+    if (h->s3) drop_graphs3d(h);          // a captured env-step carries the old parameters as kernel arguments
     return RBC_OK;
 }
 
@@ -876,7 +877,7 @@ int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double
         const size_t nc = g.nc;
         if (!s->dbg) HIP_TRY(hipMalloc(&s->dbg, (size_t)B * 4 * nc * sizeof(double)));
         HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)B * g.heaters * sizeof(float), hipMemcpyHostToDevice));
-        wall3d(h, h->d_actions, 0);
+        wall3d(h, whole_batch(h), h->d_actions, 0);
         double *cur = s->st[s->cur];
         hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
         const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
