@@ -79,9 +79,10 @@ int create3d(rbc_handle *h)
     }
     factor2(c.nx, s->plan.nx1, s->plan.nx2);
     factor2(ny, s->plan.ny1, s->plan.ny2);
-    s->fft_lds = ((size_t)2 * c.nx * ny + c.nx + ny) * sizeof(double2);
+    s->fft_lds = ((size_t)2 * rbc3::slab_row(c.nx) * ny + c.nx + ny) * sizeof(double2);
     { const int items = 8 * (c.nx > ny ? c.nx : ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
     if (h->stream2d) s->fft_threads = c.nx >= 256 ? 256 : (c.nx + 63) / 64 * 64;      // a "slab" is one row: one work item per point
+    if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_THREADS")) s->fft_threads = std::atoi(e);
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
     const size_t B = h->B;
     for (int q = 0; q < 2; ++q) {

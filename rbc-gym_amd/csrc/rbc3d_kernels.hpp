@@ -842,58 +842,65 @@ template <int N1> __device__ __forceinline__ void dftN(double *re, double *im)
     else rbc::dft8(re, im);
 }
 
+// Lanes run along LINES in both stages (consecutive lanes = consecutive lines, all at the same element): with a line stride that
+// is odd in units of 16 bytes (rows: nxp = nx | 1 complex values; columns: 1) the 16 lanes of an LDS access group fall on 16
+// different bank quads, whatever the element offsets are.  Stage 1 goes S -> D and leaves (k1, b2) at element k1 + N1 b2, so
+// that stage 2 is in place in D and ends in natural order k = k1 + N1 k2.
 template <int N1>
-__device__ inline void slab_fft(double2 *A, double2 *T, int lines, int ls, int es, const double2 *tw, int sign)
+__device__ inline void slab_fft(const double2 *S, double2 *D, int lines, int ls, int es, const double2 *tw, int sign)
 {
-    // stage 1 (in place): DFT-N1 over a for fixed (line, b2), times W_n^(b2 k1)
+    // stage 1: DFT-N1 over a for fixed (line, b2), times W_n^(b2 k1)
     for (int item = threadIdx.x; item < lines * 8; item += blockDim.x) {
-        const int line = item >> 3, b2 = item & 7;
-        double2 *base = A + line * ls + b2 * es;
+        const int b2 = item / lines, line = item - b2 * lines;
+        const double2 *src = S + line * ls + b2 * es;
         double re[N1], im[N1];
 #pragma unroll
-        for (int a = 0; a < N1; ++a) { const double2 x = base[8 * a * es]; re[a] = x.x; im[a] = x.y; }
+        for (int a = 0; a < N1; ++a) { const double2 x = src[8 * a * es]; re[a] = x.x; im[a] = x.y; }
         if (sign < 0) dftN<N1>(re, im); else dftN<N1>(im, re);
+        double2 *dst = D + line * ls + N1 * b2 * es;
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1) {
             const double2 t = tw[b2 * k1];
             const double ti = sign < 0 ? -t.y : t.y;
-            base[8 * k1 * es] = make_double2(re[k1] * t.x - im[k1] * ti, re[k1] * ti + im[k1] * t.x);
+            dst[k1 * es] = make_double2(re[k1] * t.x - im[k1] * ti, re[k1] * ti + im[k1] * t.x);
         }
     }
     __syncthreads();
-    // stage 2 (A -> T): DFT-8 over b2 for fixed (line, k1) -> position k1 + N1*k2
+    // stage 2 (in place): DFT-8 over b2 for fixed (line, k1) -> element k1 + N1*k2
     for (int item = threadIdx.x; item < lines * N1; item += blockDim.x) {
-        const int line = item / N1, k1 = item - line * N1;
-        const double2 *src = A + line * ls + 8 * k1 * es;
+        const int k1 = item / lines, line = item - k1 * lines;
+        double2 *p = D + line * ls + k1 * es;
         double re[8], im[8];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) { const double2 x = src[b * es]; re[b] = x.x; im[b] = x.y; }
+        for (int b = 0; b < 8; ++b) { const double2 x = p[N1 * b * es]; re[b] = x.x; im[b] = x.y; }
         if (sign < 0) rbc::dft8(re, im); else rbc::dft8(im, re);
-        double2 *dst = T + line * ls + k1 * es;
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) dst[N1 * k2 * es] = make_double2(re[k2], im[k2]);
+        for (int k2 = 0; k2 < 8; ++k2) p[N1 * k2 * es] = make_double2(re[k2], im[k2]);
     }
     __syncthreads();
 }
 
-// 2D transform of the slab in A (result back in A); falls back to the generic routine for other sizes
+// padded row length of a slab in LDS (complex values): odd, see slab_fft
+__host__ __device__ __forceinline__ int slab_row(int nx) { return nx | 1; }
+
+// 2D transform of the slab in A (rows of slab_row(nx) values; result back in A); the generic routine for other sizes
 __device__ inline void slab_fft2d(double2 *A, double2 *T, int nx, int ny, const FftPlan &pl, const double2 *twx, const double2 *twy,
                                   int sign)
 {
-    // along x: lines = rows (stride nx, element stride 1); result in T
-    bool inT;
-    if (pl.nx2 == 8 && pl.nx1 == 6) { slab_fft<6>(A, T, ny, nx, 1, twx, sign); inT = true; }
-    else if (pl.nx2 == 8 && pl.nx1 == 4) { slab_fft<4>(A, T, ny, nx, 1, twx, sign); inT = true; }
-    else if (pl.nx2 == 8 && pl.nx1 == 8) { slab_fft<8>(A, T, ny, nx, 1, twx, sign); inT = true; }
-    else { slab_dft(A, A, ny, nx, pl.nx1, pl.nx2, nx, 1, twx, sign, T); inT = false; }
-    double2 *S = inT ? T : A, *D = inT ? A : T;
-    // along y: lines = columns (stride 1, element stride nx); result in D (fast path) or S (generic)
-    if (pl.ny2 == 8 && pl.ny1 == 6) slab_fft<6>(S, D, nx, 1, nx, twy, sign);
-    else if (pl.ny2 == 8 && pl.ny1 == 4) slab_fft<4>(S, D, nx, 1, nx, twy, sign);
-    else if (pl.ny2 == 8 && pl.ny1 == 8) slab_fft<8>(S, D, nx, 1, nx, twy, sign);
-    else { slab_dft(S, S, nx, ny, pl.ny1, pl.ny2, 1, nx, twy, sign, D); D = S; }
-    if (D != A) {
-        for (int idx = threadIdx.x; idx < nx * ny; idx += blockDim.x) A[idx] = D[idx];
+    const int nxp = slab_row(nx);
+    double2 *S = A, *D = T;
+    // along x: lines = rows (stride nxp, element stride 1)
+    if (pl.nx2 == 8 && pl.nx1 == 6) { slab_fft<6>(S, D, ny, nxp, 1, twx, sign); double2 *t = S; S = D; D = t; }
+    else if (pl.nx2 == 8 && pl.nx1 == 4) { slab_fft<4>(S, D, ny, nxp, 1, twx, sign); double2 *t = S; S = D; D = t; }
+    else if (pl.nx2 == 8 && pl.nx1 == 8) { slab_fft<8>(S, D, ny, nxp, 1, twx, sign); double2 *t = S; S = D; D = t; }
+    else slab_dft(S, S, ny, nx, pl.nx1, pl.nx2, nxp, 1, twx, sign, D);
+    // along y: lines = columns (stride 1, element stride nxp)
+    if (pl.ny2 == 8 && pl.ny1 == 6) { slab_fft<6>(S, D, nx, 1, nxp, twy, sign); double2 *t = S; S = D; D = t; }
+    else if (pl.ny2 == 8 && pl.ny1 == 4) { slab_fft<4>(S, D, nx, 1, nxp, twy, sign); double2 *t = S; S = D; D = t; }
+    else if (pl.ny2 == 8 && pl.ny1 == 8) { slab_fft<8>(S, D, nx, 1, nxp, twy, sign); double2 *t = S; S = D; D = t; }
+    else slab_dft(S, S, nx, ny, pl.ny1, pl.ny2, 1, nxp, twy, sign, D);
+    if (S != A) {
+        for (int idx = threadIdx.x; idx < nxp * ny; idx += blockDim.x) A[idx] = S[idx];
         __syncthreads();
     }
 }
@@ -905,7 +912,8 @@ __global__ void k3_rhs_fft(Geo3 g, FftPlan pl, const double *st, double2 *spec, 
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
     const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny;
     const int env = blockIdx.x / nz, k = blockIdx.x - env * nz;
-    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
+    double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
     for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
     for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
     const double *sb = st + (size_t)env * g.env_stride;
@@ -918,12 +926,12 @@ __global__ void k3_rhs_fft(Geo3 g, FftPlan pl, const double *st, double2 *spec, 
         const double wt = (k + 1 < nz) ? w[c + pln] : 0.0;
         const double wb = (k > 0) ? w[c] : 0.0;
         const double d = (u[(size_t)k * pln + j * nx + ip] - u[c]) * g.rdx + (v[(size_t)k * pln + jp * nx + i] - v[c]) * g.rdy + (wt - wb) * g.rdz;
-        A[idx] = make_double2(d * rdt, 0.0);
+        A[j * nxp + i] = make_double2(d * rdt, 0.0);
     }
     __syncthreads();
     slab_fft2d(A, T, nx, ny, pl, twx, twy, -1);
     double2 *o = spec + ((size_t)env * nz + k) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx];
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; o[idx] = A[idx + j * (nxp - nx)]; }
 }
 
 // z sweep per (env, n, m): tab[k][n][m] = 1/pivot; mean mode pinned (its z-mean is removed on output)
@@ -984,16 +992,17 @@ __global__ void k3_ifft(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
     const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny;
     const int env = blockIdx.x / nz, k = blockIdx.x - env * nz;
-    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
+    double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
     for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
     for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
     const double2 *in = spec + ((size_t)env * nz + k) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) A[idx] = in[idx];
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; A[idx + j * (nxp - nx)] = in[idx]; }
     __syncthreads();
     slab_fft2d(A, T, nx, ny, pl, twx, twy, +1);
     const double sc = 1.0 / (double)pln;
     double *o = phi + ((size_t)env * nz + k) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx].x * sc;
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; o[idx] = A[idx + j * (nxp - nx)].x * sc; }
 }
 
 
@@ -1009,7 +1018,8 @@ __global__ void k3_rhs_fft_pair(Geo3 g, FftPlan pl, const double *st, double2 *s
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
     const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2;
     const int env = blockIdx.x / half, k = blockIdx.x - env * half, km = nz - 1 - k;
-    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
+    double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
     for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
     for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
     const double *sb = st + (size_t)env * g.env_stride;
@@ -1025,12 +1035,12 @@ __global__ void k3_rhs_fft_pair(Geo3 g, FftPlan pl, const double *st, double2 *s
             const double wb = (kk > 0) ? w[c + idx] : 0.0;
             return (u[c + e] - u[c + idx]) * g.rdx + (v[c + n] - v[c + idx]) * g.rdy + (wt - wb) * g.rdz;
         };
-        A[idx] = make_double2(div(k) * rdt, div(km) * rdt);
+        A[j * nxp + i] = make_double2(div(k) * rdt, div(km) * rdt);
     }
     __syncthreads();
     slab_fft2d(A, T, nx, ny, pl, twx, twy, -1);
     double2 *o = spec + ((size_t)env * half + k) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) o[idx] = A[idx];
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; o[idx] = A[idx + j * (nxp - nx)]; }
 }
 
 // forward elimination of the packed spectrum over k = 0..nz/2-1; the junction value also goes to jct[env][mode]
@@ -1160,16 +1170,17 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *ph
     const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2;
     const int env = blockIdx.x / half, k = blockIdx.x - env * half;
     if (mask && !mask[env]) return;                               // masked reset: this env is not being projected
-    double2 *A = sm, *T = sm + pln, *twx = sm + 2 * pln, *twy = twx + nx;
+    const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
+    double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
     for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
     for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
     const double2 *in = spec + ((size_t)env * half + k) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) A[idx] = in[idx];
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; A[idx + j * (nxp - nx)] = in[idx]; }
     __syncthreads();
     slab_fft2d(A, T, nx, ny, pl, twx, twy, +1);
     const double sc = 1.0 / (double)pln;
     double *lo = phi + ((size_t)env * nz + k) * pln, *hi = phi + ((size_t)env * nz + (nz - 1 - k)) * pln;
-    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { lo[idx] = A[idx].x * sc; hi[idx] = A[idx].y * sc; }
+    for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; const double2 a = A[idx + j * (nxp - nx)]; lo[idx] = a.x * sc; hi[idx] = a.y * sc; }
     if (!st) return;
     double *sb = st + (size_t)env * g.env_stride;
     double *ulo = sb + g.nc + (size_t)k * pln, *uhi = sb + g.nc + (size_t)(nz - 1 - k) * pln;
@@ -1188,8 +1199,8 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *ph
             const int idx = base + q * blockDim.x;
             if (idx < pln) {
                 const int j = idx / nx, i = idx - j * nx;
-                const int w_ = j * nx + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nx + i;
-                const double2 c = A[idx], pw = A[w_], ps = A[s_];
+                const int w_ = j * nxp + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nxp + i;
+                const double2 c = A[j * nxp + i], pw = A[w_], ps = A[s_];
                 // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
                 ulo[idx] = ul[q] - (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] = uh[q] - (c.y * sc - pw.y * sc) * g.rdx * dts;
                 vlo[idx] = vl[q] - (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] = vh[q] - (c.y * sc - ps.y * sc) * g.rdy * dts;
