@@ -261,14 +261,15 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
                (ty + 6) * g.nx <= 2 * thr;
     };
     // LDS-tiled tendency kernels (planes staged once per level; first half of the grid: (u, v), second half: (w, b)).  Tile shapes
-    // (rows of y x levels of z): with several env groups in flight a launch only has to fill its share of the chip, and tall
-    // tiles win (fewer chunk prologues: the z windows of a column are loaded once per chunk); a single chain needs the workgroup
-    // count of 16 x 4.  RBC_TILE_SHAPE=16x16|16x8|16x4|8x8 forces one (A/B runs).
+    // (rows of y x levels of z): tall tiles win (fewer chunk prologues: the z windows of a column are loaded once per chunk) as
+    // long as the launch still has about a hundred workgroups (a group of 8 configs[4] envs: 96); small batches take
+    // 16 x 4.  RBC_TILE_SHAPE=16x16|16x8|16x4|8x8 forces one (A/B runs).
     const char *tshape = std::getenv("RBC_TILE_SHAPE");
     auto want = [&](const char *name, bool dflt) { return tshape ? std::strcmp(tshape, name) == 0 : dflt; };
     int shape = 0;
-    if (want("16x16", s->groups > 1) && tiles_fit(16, 16, 768)) shape = 1;
-    else if (want("16x8", s->groups > 1) && tiles_fit(16, 8, 768)) shape = 2;
+    auto wgs = [&](int ty, int kt) { return 2 * B * (g.ny / ty) * (g.nz / kt); };       // workgroups of one launch
+    if (want("16x16", wgs(16, 16) >= 96) && tiles_fit(16, 16, 768)) shape = 1;
+    else if (want("16x8", wgs(16, 8) >= 96) && tiles_fit(16, 8, 768)) shape = 2;
     else if (want("16x4", true) && tiles_fit(16, 4, 768)) shape = 3;
     else if (want("8x8", true) && tiles_fit(8, 8, 512)) shape = 4;
     for (int n = 0; n < nsub; ++n) {

@@ -359,13 +359,14 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
     """The batch is cut into env groups whose stage chains run on their own streams, replayed as one captured graph (default:
     4 groups from B = 16 up, tall 16 x 16 tiles).  Against the single chain on the handle's stream (RBC_3D_GROUPS=1, no graph)
     with the same tile shape nothing may change, bit for bit: three env-steps (both ping-pong parities of the graph and a
-    replay), and uneven groups (16 envs in 3 groups: 6 + 6 + 4) launched without a graph.  Other tile shapes are other
-    instantiations of the same expressions (the compiler's fma contraction may differ): round-off."""
+    replay), and uneven groups (16 envs in 3 groups: 6 + 6 + 4) launched without a graph.  Other tile shapes (the default
+    picks one by the workgroup count of a launch) are other instantiations of the same expressions (the compiler's fma
+    contraction may differ): round-off."""
     B, shape = 16, (16, 32, 32)
     act = np.random.default_rng(8).uniform(-1, 1, (3, B, 8, 8)).astype(np.float32)
     outs = []
-    for env in (dict(RBC_3D_GROUPS="1", RBC_TILE_SHAPE="16x16"), dict(), dict(RBC_3D_GROUPS="3", RBC_USE_GRAPH="0", RBC_TILE_SHAPE="16x16"),
-                dict(RBC_3D_GROUPS="1"), dict(RBC_3D_GROUPS="2", RBC_TILE_SHAPE="16x8")):
+    for env in (dict(RBC_3D_GROUPS="1", RBC_TILE_SHAPE="16x16"), dict(RBC_TILE_SHAPE="16x16"), dict(RBC_3D_GROUPS="3", RBC_USE_GRAPH="0", RBC_TILE_SHAPE="16x16"),
+                dict(), dict(RBC_3D_GROUPS="1"), dict(RBC_3D_GROUPS="2", RBC_TILE_SHAPE="16x8")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         sim = native.NativeSim3D(batch=B, shape=shape, domain=DOMAIN, ra=5000.0, dt_control=0.05, dt_solver=0.01, random_kick=0.2)
