@@ -12,9 +12,13 @@ struct rbc3_state {
     double *gm = nullptr, *phy = nullptr, *phi = nullptr, *tab = nullptr, *actT = nullptr, *dbg = nullptr;
     double2 *jct = nullptr;            // junction values of the packed z solve, [env][mode]
     double2 *spec = nullptr;
+    double2 *tw = nullptr;             // FFT twiddle table (FftPlan::tw)
     double *out_part = nullptr;        // k3_output: per-env partial sums of its OUT_SPLIT workgroups
     unsigned int *out_arrive = nullptr;
     size_t fft_lds = 0;
+    int thr2d = 256;
+    int rows2d = 0;                    // streaming-2D: rows (each packed with its mirror) per FFT workgroup, 0 = per-slab kernels
+    size_t fft2d_lds = 0;
     int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
     double tff = 1.0;
     // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" overrides them for the
@@ -39,7 +43,7 @@ namespace {
 
 void factor2(int n, int &n1, int &n2)
 {
-    if (n == 32 || n == 48 || n == 64) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8)
+    if (n == 32 || n == 48 || n == 64 || n == 96 || n == 128) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8; the y pass is instantiated up to 64)
     n1 = 1;
     for (int d = 1; d * d <= n; ++d)
         if (n % d == 0) n1 = d;
@@ -83,6 +87,17 @@ int create3d(rbc_handle *h)
     { const int items = 8 * (c.nx > ny ? c.nx : ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
     if (h->stream2d) s->fft_threads = c.nx >= 256 ? 256 : (c.nx + 63) / 64 * 64;      // a "slab" is one row: one work item per point
     if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_THREADS")) s->fft_threads = std::atoi(e);
+    if (h->stream2d && c.nz % 2 == 0 && !h->no_pair) {      // several row pairs per workgroup (k2s_rhs_fft_pair / k2s_ifft_pair)
+        int R = 16;
+        if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_ROWS")) R = std::atoi(e);
+        if (const char *e = std::getenv("RBC_EXPERIMENT_FFT2D_THREADS")) s->thr2d = std::atoi(e);
+        if (s->thr2d > 256 || s->thr2d < 64) s->thr2d = 256;          // the kernels' launch bound
+        while (R > 1 && ((c.nz / 2) % R != 0 || (size_t)(2 * R * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2) > 128 * 1024)) R /= 2;
+        s->rows2d = R < 1 ? 1 : R;
+        s->fft2d_lds = (size_t)(2 * s->rows2d * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
+        HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_rhs_fft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft2d_lds));
+        HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_ifft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft2d_lds));
+    }
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
     const size_t B = h->B;
     for (int q = 0; q < 2; ++q) {
@@ -95,6 +110,10 @@ int create3d(rbc_handle *h)
     HIP3(hipMalloc(&s->phi, B * (size_t)g.nc * sizeof(double)));
     HIP3(hipMalloc(&s->spec, B * (size_t)g.nc * sizeof(double2)));
     HIP3(hipMalloc(&s->jct, B * (size_t)g.nx * g.ny * sizeof(double2)));
+    HIP3(hipMalloc(&s->tw, (size_t)(g.nx + g.ny) * sizeof(double2)));
+    hipLaunchKernelGGL(rbc3::k3_twiddles, dim3((unsigned)((g.nx + g.ny + 127) / 128)), dim3(128), 0, h->stream, s->tw, g.nx, g.ny);
+    HIP3(hipGetLastError());
+    s->plan.tw = s->tw;
     HIP3(hipMalloc(&s->out_part, B * 2 * rbc3::OUT_SPLIT * sizeof(double)));
     HIP3(hipMalloc(&s->out_arrive, B * sizeof(unsigned int)));
     HIP3(hipMemset(s->out_arrive, 0, B * sizeof(unsigned int)));
@@ -158,7 +177,7 @@ void destroy3d(rbc_handle *h)
     for (hipStream_t q : s->gstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : s->gdone) if (e) (void)hipEventDestroy(e);
     if (s->gstart) (void)hipEventDestroy(s->gstart);
-    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
+    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -182,14 +201,17 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
     if (g.nz % 2 == 0 && !h->no_pair) {      // mirror slabs packed as one complex transform, z solve on the packed spectrum
         double2 *spec = s->spec + (size_t)q.e0 * (g.nz / 2) * pln, *jct = s->jct + (size_t)q.e0 * pln;
         const dim3 gm_ = grid_for((size_t)B * pln, 128);
-        hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, buf, spec, dts);
+        const int thr2d = s->thr2d;
+        if (s->rows2d) hipLaunchKernelGGL(rbc3::k2s_rhs_fft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, buf, spec, dts, s->rows2d);
+        else hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, buf, spec, dts);
         if (g.nz == 32 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<16>, gm_, dim3(128), 0, q.st, g, spec, s->tab, B);
         else if (g.nz == 16 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<8>, gm_, dim3(128), 0, q.st, g, spec, s->tab, B);
         else {
             hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, q.st, g, spec, jct, s->tab, B);
             hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, q.st, g, spec, jct, s->tab, B);
         }
-        hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
+        if (s->rows2d) hipLaunchKernelGGL(rbc3::k2s_ifft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
+        else hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
         hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
         HIP3(hipGetLastError());
         return RBC_OK;

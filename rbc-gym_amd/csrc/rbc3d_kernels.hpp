@@ -803,7 +803,20 @@ __device__ inline void slab_dft(const double2 *src, double2 *dst, int lines, int
     __syncthreads();
 }
 
-struct FftPlan { int nx1, nx2, ny1, ny2; };
+struct FftPlan {
+    int nx1, nx2, ny1, ny2;
+    const double2 *tw;          // twiddles e^{+2 pi i t / n}: nx values for the rows, then ny for the columns (k3_twiddles)
+};
+
+__global__ void k3_twiddles(double2 *tw, int nx, int ny)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx + ny) return;
+    const int n = (t < nx) ? nx : ny, q = (t < nx) ? t : t - nx;
+    double s, c;
+    sincospi(2.0 * q / n, &s, &c);
+    tw[t] = make_double2(c, s);
+}
 
 // ---- register-blocked slab FFT for n = N1*8 (N1 in {4,6,8}: n = 32, 48, 64) ----------------------
 // Same two-factor Cooley-Tukey as slab_dft, but each work item holds a whole small DFT in registers
@@ -837,9 +850,13 @@ __device__ __forceinline__ void dft6(double *re, double *im)
 }
 template <int N1> __device__ __forceinline__ void dftN(double *re, double *im)
 {
+    static_assert(N1 == 4 || N1 == 6 || N1 == 8 || N1 == 12 || N1 == 16 || N1 == 24, "register-blocked slab FFT: n = 8 * {4, 6, 8, 12, 16, 24}");
     if (N1 == 4) dft4(re, im);
     else if (N1 == 6) dft6(re, im);
-    else rbc::dft8(re, im);
+    else if (N1 == 8) rbc::dft8(re, im);
+    else if (N1 == 12) rbc::dft12(re, im);
+    else if (N1 == 16) rbc::dft16(re, im);
+    else rbc::dft24(re, im);
 }
 
 // Lanes run along LINES in both stages (consecutive lanes = consecutive lines, all at the same element): with a line stride that
@@ -893,7 +910,7 @@ __device__ inline void slab_fft2d(double2 *A, double2 *T, int nx, int ny, const 
     if (pl.nx2 == 8 && pl.nx1 == 6) { slab_fft<6>(S, D, ny, nxp, 1, twx, sign); double2 *t = S; S = D; D = t; }
     else if (pl.nx2 == 8 && pl.nx1 == 4) { slab_fft<4>(S, D, ny, nxp, 1, twx, sign); double2 *t = S; S = D; D = t; }
     else if (pl.nx2 == 8 && pl.nx1 == 8) { slab_fft<8>(S, D, ny, nxp, 1, twx, sign); double2 *t = S; S = D; D = t; }
-    else slab_dft(S, S, ny, nx, pl.nx1, pl.nx2, nxp, 1, twx, sign, D);
+    else slab_dft(S, S, ny, nx, pl.nx1, pl.nx2, nxp, 1, twx, sign, D);      // (the long rows of streaming-2D grids: slab_fft_rows below)
     // along y: lines = columns (stride 1, element stride nxp)
     if (pl.ny2 == 8 && pl.ny1 == 6) { slab_fft<6>(S, D, nx, 1, nxp, twy, sign); double2 *t = S; S = D; D = t; }
     else if (pl.ny2 == 8 && pl.ny1 == 4) { slab_fft<4>(S, D, nx, 1, nxp, twy, sign); double2 *t = S; S = D; D = t; }
@@ -914,8 +931,7 @@ __global__ void k3_rhs_fft(Geo3 g, FftPlan pl, const double *st, double2 *spec, 
     const int env = blockIdx.x / nz, k = blockIdx.x - env * nz;
     const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
     double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
-    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
-    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < nx + ny; t += blockDim.x) twx[t] = pl.tw[t];      // twy = twx + nx, like the table
     const double *sb = st + (size_t)env * g.env_stride;
     const double *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
     const double rdt = 1.0 / dts;
@@ -994,8 +1010,7 @@ __global__ void k3_ifft(Geo3 g, FftPlan pl, const double2 *spec, double *phi)
     const int env = blockIdx.x / nz, k = blockIdx.x - env * nz;
     const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
     double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
-    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
-    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < nx + ny; t += blockDim.x) twx[t] = pl.tw[t];      // twy = twx + nx, like the table
     const double2 *in = spec + ((size_t)env * nz + k) * pln;
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; A[idx + j * (nxp - nx)] = in[idx]; }
     __syncthreads();
@@ -1020,8 +1035,7 @@ __global__ void k3_rhs_fft_pair(Geo3 g, FftPlan pl, const double *st, double2 *s
     const int env = blockIdx.x / half, k = blockIdx.x - env * half, km = nz - 1 - k;
     const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
     double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
-    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
-    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < nx + ny; t += blockDim.x) twx[t] = pl.tw[t];      // twy = twx + nx, like the table
     const double *sb = st + (size_t)env * g.env_stride;
     const double *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
     const double rdt = 1.0 / dts;
@@ -1172,8 +1186,7 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *ph
     if (mask && !mask[env]) return;                               // masked reset: this env is not being projected
     const int nxp = slab_row(nx), lpl = nxp * ny;                  // LDS slab: rows padded to nxp values
     double2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
-    for (int t = threadIdx.x; t < nx; t += blockDim.x) { double s, c; sincospi(2.0 * t / nx, &s, &c); twx[t] = make_double2(c, s); }
-    for (int t = threadIdx.x; t < ny; t += blockDim.x) { double s, c; sincospi(2.0 * t / ny, &s, &c); twy[t] = make_double2(c, s); }
+    for (int t = threadIdx.x; t < nx + ny; t += blockDim.x) twx[t] = pl.tw[t];      // twy = twx + nx, like the table
     const double2 *in = spec + ((size_t)env * half + k) * pln;
     for (int idx = threadIdx.x; idx < pln; idx += blockDim.x) { const int j = idx / nx; A[idx + j * (nxp - nx)] = in[idx]; }
     __syncthreads();
@@ -1325,6 +1338,75 @@ __global__ void __launch_bounds__(256) k3_output(Geo3 g, const double *st, const
 // (collate_actions_colin), the 2D random initial condition, and the 2D outputs (5-channel float32 state / observations,
 // the two Nusselt numbers of rbc_sim2D_api.jl:142-163).
 // =====================================================================================================================
+
+// x transform of `lines` rows held in LDS (rows of slab_row(nx) values), result pointer returned (S or D)
+__device__ inline double2 *slab_fft_rows(double2 *S, double2 *D, int lines, int nx, const FftPlan &pl, const double2 *twx, int sign)
+{
+    const int nxp = slab_row(nx);
+#define RBC_ROWS(N1_) if (pl.nx2 == 8 && pl.nx1 == N1_) { slab_fft<N1_>(S, D, lines, nxp, 1, twx, sign); return D; }
+    RBC_ROWS(4) RBC_ROWS(6) RBC_ROWS(8) RBC_ROWS(12) RBC_ROWS(16)      // (a DFT-24 in registers costs the kernel its occupancy)
+#undef RBC_ROWS
+    slab_dft(S, S, lines, nx, pl.nx1, pl.nx2, nxp, 1, twx, sign, D);
+    return S;
+}
+#if RBC_EXPERIMENT_NOFFT
+#define slab_fft_rows(S_, D_, l_, n_, p_, t_, s_) (S_)          /* timing experiment only (WRONG numerics) */
+#endif
+
+// Projection of a streaming-2D state (ny = 1): a "slab" is one row, so a workgroup takes R consecutive rows k0 .. k0+R-1 of one
+// env, each packed with its mirror row nz-1-k as in k3_rhs_fft_pair, and transforms them together (R lines of the row FFT).
+// grid = B * (nz/2 / R) workgroups; same arithmetic per value as the 3D kernels (divergence, scaling, correction order).
+__global__ void __launch_bounds__(256, 3) k2s_rhs_fft_pair(Geo3 g, FftPlan pl, const double *st, double2 *spec, double dts, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, nz = g.nz, half = nz / 2, nxp = slab_row(nx), per = half / R;
+    const int env = blockIdx.x / per, k0 = (blockIdx.x - env * per) * R;
+    double2 *A = sm, *T = sm + R * nxp, *twx = sm + 2 * R * nxp;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) twx[t] = pl.tw[t];
+    const double *sb = st + (size_t)env * g.env_stride;
+    const double *u = sb + g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double rdt = 1.0 / dts;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) {
+        const int r = idx / nx, i = idx - r * nx, k = k0 + r, km = nz - 1 - k;
+        const int ip = (i + 1 == nx) ? 0 : i + 1;
+        auto div = [&](int kk) -> double {
+            const size_t c = (size_t)kk * nx;
+            const double wt = (kk + 1 < nz) ? w[c + nx + i] : 0.0;
+            const double wb = (kk > 0) ? w[c + i] : 0.0;
+            return (u[c + ip] - u[c + i]) * g.rdx + (wt - wb) * g.rdz;
+        };
+        A[r * nxp + i] = make_double2(div(k) * rdt, div(km) * rdt);
+    }
+    __syncthreads();
+    const double2 *S = slab_fft_rows(A, T, R, nx, pl, twx, -1);
+    double2 *o = spec + ((size_t)env * half + k0) * nx;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) { const int r = idx / nx, i = idx - r * nx; o[idx] = S[r * nxp + i]; }
+}
+
+__global__ void __launch_bounds__(256, 3) k2s_ifft_pair(Geo3 g, FftPlan pl, const double2 *spec, double *phi, double *st, double dts, const uint8_t *mask, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, nz = g.nz, half = nz / 2, nxp = slab_row(nx), per = half / R;
+    const int env = blockIdx.x / per, k0 = (blockIdx.x - env * per) * R;
+    if (mask && !mask[env]) return;                               // masked reset: this env is not being projected
+    double2 *A = sm, *T = sm + R * nxp, *twx = sm + 2 * R * nxp;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) twx[t] = pl.tw[t];
+    const double2 *in = spec + ((size_t)env * half + k0) * nx;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) { const int r = idx / nx, i = idx - r * nx; A[r * nxp + i] = in[idx]; }
+    __syncthreads();
+    const double2 *S = slab_fft_rows(A, T, R, nx, pl, twx, +1);
+    const double sc = 1.0 / (double)nx;
+    double *sb = st + (size_t)env * g.env_stride;
+    double *ph = phi + (size_t)env * g.nc, *u = sb + g.nc;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) {
+        const int r = idx / nx, i = idx - r * nx, k = k0 + r, km = nz - 1 - k;
+        const double2 c = S[r * nxp + i], pw = S[r * nxp + ((i == 0) ? nx - 1 : i - 1)];
+        ph[(size_t)k * nx + i] = c.x * sc; ph[(size_t)km * nx + i] = c.y * sc;
+        // same operation order as k3_correct / k3_ifft_pair: (phi_c - phi_w) * rdx * dts on the normalised potentials
+        u[(size_t)k * nx + i] -= (c.x * sc - pw.x * sc) * g.rdx * dts;
+        u[(size_t)km * nx + i] -= (c.y * sc - pw.y * sc) * g.rdx * dts;
+    }
+}
 
 // bottom-plate temperature of every column: collate_actions_colin (rbc_sim2D.jl:87-133), same arithmetic as rbc2d_kernel
 __global__ void __launch_bounds__(128) k2s_wall(Geo3 g, const float *actions, double *wall, int zero_action, int B)
