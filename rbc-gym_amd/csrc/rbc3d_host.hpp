@@ -9,6 +9,8 @@ struct rbc3_state {
     rbc3::FftPlan plan;
     double *st[2] = {nullptr, nullptr};   // ping-pong state buffers [B][b|u|v|w]
     int cur = 0;
+    double *phy2 = nullptr;            // streaming-2D: pHY' of the stage before the last (k2s_output's correction of pNHS)
+    bool unsplit_phi = false;          // the potential in `phi` belongs to un-split tendencies (set by a step, cleared by a reset)
     double *gm = nullptr, *phy = nullptr, *phi = nullptr, *tab = nullptr, *actT = nullptr, *dbg = nullptr;
     double2 *jct = nullptr;            // junction values of the packed z solve, [env][mode]
     double2 *spec = nullptr;
@@ -108,6 +110,7 @@ int create3d(rbc_handle *h)
     HIP3(hipMemset(s->gm, 0, B * g.env_stride * sizeof(double)));
     HIP3(hipMalloc(&s->phy, B * (size_t)g.nc * sizeof(double)));
     HIP3(hipMalloc(&s->phi, B * (size_t)g.nc * sizeof(double)));
+    if (h->stream2d) HIP3(hipMalloc(&s->phy2, B * (size_t)g.nc * sizeof(double)));
     HIP3(hipMalloc(&s->spec, B * (size_t)g.nc * sizeof(double2)));
     HIP3(hipMalloc(&s->jct, B * (size_t)g.nx * g.ny * sizeof(double2)));
     HIP3(hipMalloc(&s->tw, (size_t)(g.nx + g.ny) * sizeof(double2)));
@@ -177,7 +180,7 @@ void destroy3d(rbc_handle *h)
     for (hipStream_t q : s->gstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : s->gdone) if (e) (void)hipEventDestroy(e);
     if (s->gstart) (void)hipEventDestroy(s->gstart);
-    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
+    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phy2, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -239,8 +242,10 @@ int output3d(rbc_handle *h, const rbc3_grp &q, int which, const uint8_t *mask)
         o.obs_nx = h->cfg.obs_nx; o.obs_nz = h->cfg.obs_nz; o.write_state = h->cfg.write_state;
         o.obs_norm = h->obs_norm; o.obs_clip = h->obs_clip; o.obs_maxval = h->obs_maxval;
         for (int c = 0; c < 5; ++c) { o.obs_min[c] = h->obs_min[c]; o.obs_rng[c] = h->obs_rng[c]; }
+        const double gs = s->gam[2] + s->zet[2];
         hipLaunchKernelGGL(rbc3::k2s_output, dim3(q.B), dim3(256), (2 * (size_t)g.nz + 256) * sizeof(double), q.st, g, st, s->phi + (size_t)q.e0 * g.nc,
-                           h->d_ra + (size_t)q.e0 * 2, o, mk);
+                           h->d_ra + (size_t)q.e0 * 2, o, mk, s->unsplit_phi ? s->phy + (size_t)q.e0 * g.nc : (const double *)nullptr,
+                           s->phy2 + (size_t)q.e0 * g.nc, s->gam[2] / gs, s->zet[2] / gs);
         HIP3(hipGetLastError());
         return RBC_OK;
     }
@@ -294,6 +299,8 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
     else if (want("16x8", wgs(16, 8) >= 96) && tiles_fit(16, 8, 768)) shape = 2;
     else if (want("16x4", true) && tiles_fit(16, 4, 768)) shape = 3;
     else if (want("8x8", true) && tiles_fit(8, 8, 512)) shape = 4;
+    // streaming-2D mode: the same bodies with one-row planes (FLAT), a workgroup = one row of nx threads marching 16 / 8 / 4 levels
+    if (h->stream2d && !h->no_tile && g.nx <= 256 && g.nz % 4 == 0) shape = (g.nz % 16 == 0) ? 5 : ((g.nz % 8 == 0) ? 6 : 7);
     for (int n = 0; n < nsub; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;
         for (int ph = 0; ph < 3; ++ph) {
@@ -301,6 +308,9 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             const int store_g = (ph != 2);                     // the last stage's tendencies are never read again (zeta^1 = 0)
             if (!shape)                                        // the fallback kernels use the hydrostatic split (pHY' column scan)
                 hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, q.st, g, cur, phy, B);
+            else if (h->stream2d && n == nsub - 1 && ph >= 1)  // un-split tendencies: the two scans k2s_output needs to return pNHS
+                hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, q.st, g, cur,
+                                   ph == 2 ? phy : s->phy2 + (size_t)q.e0 * g.nc, B);
 #define RBC_TILE_LAUNCH(TY, KT, THR, WAVES)                                                                                              \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
@@ -312,6 +322,15 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             else if (shape == 3) RBC_TILE_LAUNCH(16, 4, 768, 3)
             else if (shape == 4) RBC_TILE_LAUNCH(8, 8, 512, 2)
 #undef RBC_TILE_LAUNCH
+#define RBC_FLAT_LAUNCH(KT)                                                                                                              \
+            {                                                                                                                            \
+                const dim3 gt((unsigned)(2 * (size_t)B * (g.nz / KT))), bt(g.nx);                                                         \
+                hipLaunchKernelGGL((rbc3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(double), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
+            }
+            else if (shape == 5) RBC_FLAT_LAUNCH(16)
+            else if (shape == 6) RBC_FLAT_LAUNCH(8)
+            else if (shape == 7) RBC_FLAT_LAUNCH(4)
+#undef RBC_FLAT_LAUNCH
             else if (g.nz % rbc3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
                 const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / rbc3::KC3), 128));
                 hipLaunchKernelGGL(rbc3::k3_tend_march<0>, gm_, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B);
@@ -331,6 +350,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
         }
     }
     HIP3(hipGetLastError());
+    s->unsplit_phi = h->stream2d && shape != 0;
     *which_out = which;
     return RBC_OK;
 }
@@ -404,6 +424,7 @@ int finish_reset3d(rbc_handle *h)
     rbc3_state *s = h->s3;
     const rbc3_grp q = whole_batch(h);
     wall3d(h, q, nullptr, 1);
+    s->unsplit_phi = false;                                      // set!'s projection: phi is the potential itself
     if (h->stream2d)
         hipLaunchKernelGGL(rbc3::k2s_clear_v, grid_for((size_t)h->B * s->g.nc, 256), dim3(256), 0, h->stream, s->g, s->st[0], s->st[1], h->d_mask, h->B);
     if (int rc = project3d(h, q, s->cur, 1.0, h->d_mask)) return rc;

@@ -457,13 +457,18 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const double *cur, 
 // are never read again (zeta^1 = 0).
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
 
-template <int TY3, int KT3>
+// FLAT (streaming-2D mode, ny = 1): a plane is ONE row of up to NXP values (no y halo), every y offset of a stencil read
+// aliases that row, and everything that involves v or a y-difference is compiled out (it is identically zero).
+template <int TY3, int KT3, int NXP = NXP3, bool FLAT = false>
 struct TileGeo {
-    static constexpr int PLANE3 = (TY3 + 6) * NXP3;
+    static constexpr int ROWS3 = FLAT ? 1 : TY3 + 6;
+    static constexpr int PLANE3 = ROWS3 * NXP;
+    static constexpr int NXPAD = NXP;
+    static constexpr bool IS_FLAT = FLAT;
     int nx, ny, nz, pl, rows, plane, tiles, chunks, env, j0, k0, i, jl, j, tid, nthreads;
     __device__ __forceinline__ TileGeo(const Geo3 &g, int blk)
     {
-        nx = g.nx; ny = g.ny; nz = g.nz; pl = nx * ny; rows = TY3 + 6; plane = rows * nx;
+        nx = g.nx; ny = g.ny; nz = g.nz; pl = nx * ny; rows = ROWS3; plane = rows * nx;
         tiles = ny / TY3; chunks = nz / KT3;
         const int zc = blk % chunks, yt = (blk / chunks) % tiles;
         env = blk / (chunks * tiles); j0 = yt * TY3; k0 = zc * KT3;
@@ -472,6 +477,7 @@ struct TileGeo {
     // global offset (inside one level) of tile element idx = row * nx + column
     __device__ __forceinline__ int src(int idx) const
     {
+        if (FLAT) return idx;
         const int r = idx / nx, c = idx - r * nx;
         int jy = j0 - 3 + r; jy += (jy < 0) ? ny : 0; jy -= (jy >= ny) ? ny : 0;
         return jy * nx + c;
@@ -490,20 +496,23 @@ __device__ __forceinline__ void tile_store(const TG &t, double *dst, const doubl
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
         const int idx = t.tid + q * t.nthreads;
-        if (idx < t.plane) { const int r = idx / t.nx, c = idx - r * t.nx; dst[r * NXP3 + c] = pf[q]; }
+        if (idx < t.plane) {
+            if (TG::IS_FLAT) dst[idx] = pf[q];
+            else { const int r = idx / t.nx, c = idx - r * t.nx; dst[r * TG::NXPAD + c] = pf[q]; }
+        }
     }
 }
 
 // (u, v): blockDim = nx * TY3, B * (ny/TY3) * (nz/KT3) workgroups, LDS = 3 planes.  Two shapes are built:
 // 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
 // (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
-template <int TY3, int KT3, int NPF>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false>
 __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, double *nxt, double *gm,
                                              const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo<TY3, KT3> t(g, blk);
-    constexpr int PLANE3 = TileGeo<TY3, KT3>::PLANE3;
+    const TileGeo<TY3, KT3, NXP, FLAT> t(g, blk);
+    constexpr int PLANE3 = TileGeo<TY3, KT3, NXP, FLAT>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PU = tile_sm, *PV = tile_sm + PLANE3, *PW = tile_sm + 2 * PLANE3;        // u(k), v(k), w(k+1)
     constexpr int IU = 0, IV = PLANE3, IW = 2 * PLANE3;
@@ -517,8 +526,8 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
     // one LDS address per x offset; the plane and the y offset are immediates of the ds_read
     const double *xb[7];
 #pragma unroll
-    for (int a = 0; a < 7; ++a) xb[a] = tile_sm + (t.jl + 3) * NXP3 + xi[a];
-    auto L = [&](int P, int a, int b) -> double { return xb[a + 3][P + b * NXP3]; };
+    for (int a = 0; a < 7; ++a) xb[a] = tile_sm + (FLAT ? 0 : (t.jl + 3) * NXP) + xi[a];
+    auto L = [&](int P, int a, int b) -> double { return xb[a + 3][P + (FLAT ? 0 : b * NXP)]; };
     auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
     auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
     auto own = [&](const double *f, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + col]; };
@@ -529,27 +538,33 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
     const size_t eb = (size_t)t.env * g.env_stride;
     const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
     double pfu[NPF], pfv[NPF], pfw[NPF], pfw1[NPF];
-    tile_fetch(t, u + (size_t)t.k0 * pl, pfu); tile_fetch(t, v + (size_t)t.k0 * pl, pfv);
+    tile_fetch(t, u + (size_t)t.k0 * pl, pfu);
+    if constexpr (!FLAT) tile_fetch(t, v + (size_t)t.k0 * pl, pfv);
     tile_fetch(t, w + (size_t)t.k0 * pl, pfw);
     tile_fetch(t, w + (size_t)min(t.k0 + 1, nz) * pl, pfw1);
     double winu[6], winv[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { winu[q] = own(u, t.k0 - 3 + q); winv[q] = own(v, t.k0 - 3 + q); }
+    for (int q = 0; q < 6; ++q) { winu[q] = own(u, t.k0 - 3 + q); winv[q] = FLAT ? 0.0 : own(v, t.k0 - 3 + q); }
     // per-level global operands of this thread travel one level ahead of their use, like the planes
-    double nu5 = own(u, t.k0 + 3), nv5 = own(v, t.k0 + 3);
-    double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = use_gm ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
+    double nu5 = own(u, t.k0 + 3), nv5 = FLAT ? 0.0 : own(v, t.k0 + 3);
+    double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = (use_gm && !FLAT) ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
     tile_store(t, PW, pfw);                                       // w(k0) first: bottom-face terms of the chunk
     __syncthreads();
     double fbu = 0.0, dwbu = 0.0, fdnu, fbv = 0.0, dwbv = 0.0, fdnv;
     if (t.k0 > 0) {
-        const double wc = L(IW, 0, 0), wmx = L(IW, -1, 0), wmy = L(IW, 0, -1);
+        const double wc = L(IW, 0, 0), wmx = L(IW, -1, 0);
         fbu = upw(sym4(L(IW, -2, 0), wmx, wc, L(IW, 1, 0)), zfL(winu, t.k0, nz), zfR(winu, t.k0, nz));
-        fbv = upw(sym4(L(IW, 0, -2), wmy, wc, L(IW, 0, 1)), zfL(winv, t.k0, nz), zfR(winv, t.k0, nz));
-        dwbu = wc - wmx; dwbv = wc - wmy;
+        dwbu = wc - wmx;
+        if constexpr (!FLAT) {
+            const double wmy = L(IW, 0, -1);
+            fbv = upw(sym4(L(IW, 0, -2), wmy, wc, L(IW, 0, 1)), zfL(winv, t.k0, nz), zfR(winv, t.k0, nz));
+            dwbv = wc - wmy;
+        }
         fdnu = winu[2]; fdnv = winv[2];
     } else { fdnu = ghost_lo(winu[3], 0.0); fdnv = ghost_lo(winv[3], 0.0); }
     __syncthreads();
-    tile_store(t, PU, pfu); tile_store(t, PV, pfv);
+    tile_store(t, PU, pfu);
+    if constexpr (!FLAT) tile_store(t, PV, pfv);
     tile_store(t, PW, pfw1);
     __syncthreads();
 
@@ -560,10 +575,12 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
         winu[5] = nu5; winv[5] = nv5;
         const double gpu_ = ngu, gpv_ = ngv;
         if (more) {                                               // next level's planes and operands fly under this level's arithmetic
-            tile_fetch(t, u + (size_t)(k + 1) * pl, pfu); tile_fetch(t, v + (size_t)(k + 1) * pl, pfv);
+            tile_fetch(t, u + (size_t)(k + 1) * pl, pfu);
+            if constexpr (!FLAT) tile_fetch(t, v + (size_t)(k + 1) * pl, pfv);
             tile_fetch(t, w + (size_t)min(k + 2, nz) * pl, pfw);
-            nu5 = own(u, k + 4); nv5 = own(v, k + 4);
-            if (use_gm) { ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; }
+            nu5 = own(u, k + 4);
+            if constexpr (!FLAT) nv5 = own(v, k + 4);
+            if (use_gm) { ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; if constexpr (!FLAT) ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; }
         }
         const bool top = (k + 1 >= nz);
         const double wc = top ? 0.0 : L(IW, 0, 0);
@@ -573,12 +590,15 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
             const double f0 = winu[2];
             double q7[7], c7[7];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IU, q - 3, 0); c7[q] = (q == 3) ? f0 : L(IU, 0, q - 3); }
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IU, q - 3, 0); c7[q] = (q == 3 || FLAT) ? f0 : L(IU, 0, q - 3); }
             const double fe = upw(sym4(q7[2], q7[3], q7[4], q7[5]), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
             const double fw = upw(sym4(q7[1], q7[2], q7[3], q7[4]), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
-            const double on_m = L(IV, -1, 1), on_c = L(IV, 0, 1), os_m = L(IV, -1, 0), os_c = winv[2];
-            const double fn = upw(sym4(L(IV, -2, 1), on_m, on_c, L(IV, 1, 1)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-            const double fs = upw(sym4(L(IV, -2, 0), os_m, os_c, L(IV, 1, 0)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            double on_m = 0.0, on_c = 0.0, os_m = 0.0, os_c = 0.0, fn = 0.0, fs = 0.0;      // FLAT: v == 0, no y fluxes
+            if constexpr (!FLAT) {
+                on_m = L(IV, -1, 1); on_c = L(IV, 0, 1); os_m = L(IV, -1, 0); os_c = winv[2];
+                fn = upw(sym4(L(IV, -2, 1), on_m, on_c, L(IV, 1, 1)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+                fs = upw(sym4(L(IV, -2, 0), os_m, os_c, L(IV, 1, 0)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            }
             double ft = 0.0, dwt = 0.0, fup;
             if (!top) {
                 const double wm = L(IW, -1, 0);
@@ -597,7 +617,7 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the two sections' live ranges apart
         // ---- v at (i, y-face j, k): the mirror image, `a` along y, `b` along x ----
-        {
+        if constexpr (!FLAT) {
             const double f0 = winv[2];
             double q7[7], c7[7];
 #pragma unroll
@@ -625,20 +645,22 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
         }
         if (more) {
             __syncthreads();                                      // every read of this level's planes is done
-            tile_store(t, PU, pfu); tile_store(t, PV, pfv); tile_store(t, PW, pfw);
+            tile_store(t, PU, pfu);
+            if constexpr (!FLAT) tile_store(t, PV, pfv);
+            tile_store(t, PW, pfw);
             __syncthreads();
         }
     }
 }
 
 // (w, b): same shape, LDS = 2 planes (w and b at the current level)
-template <int TY3, int KT3, int NPF>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false>
 __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, double *nxt, double *gm, const double *actT,
                                              const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo<TY3, KT3> t(g, blk);
-    constexpr int PLANE3 = TileGeo<TY3, KT3>::PLANE3;
+    const TileGeo<TY3, KT3, NXP, FLAT> t(g, blk);
+    constexpr int PLANE3 = TileGeo<TY3, KT3, NXP, FLAT>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PW = tile_sm, *PB = tile_sm + PLANE3;
     constexpr int IW = 0, IB = PLANE3;
@@ -653,8 +675,8 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
     const int colN = ((t.j + 1 == t.ny) ? 0 : t.j + 1) * nx + t.i;   // column (i, j+1)
     const double *xb[7];
 #pragma unroll
-    for (int a = 0; a < 7; ++a) xb[a] = tile_sm + (t.jl + 3) * NXP3 + xi[a];
-    auto L = [&](int P, int a, int bb) -> double { return xb[a + 3][P + bb * NXP3]; };
+    for (int a = 0; a < 7; ++a) xb[a] = tile_sm + (FLAT ? 0 : (t.jl + 3) * NXP) + xi[a];
+    auto L = [&](int P, int a, int bb) -> double { return xb[a + 3][P + (FLAT ? 0 : bb * NXP)]; };
     auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
     auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
     auto cen = [&](const double *f, int c, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + c]; };
@@ -670,11 +692,11 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
     for (int q = 0; q < 6; ++q) {
         winw[q] = fac(t.k0 - 3 + q); winb[q] = cen(b, col, t.k0 - 3 + q);
         au[q] = cen(u, col, t.k0 - 4 + q); eu[q] = cen(u, colE, t.k0 - 4 + q);
-        av[q] = cen(v, col, t.k0 - 4 + q); ev[q] = cen(v, colN, t.k0 - 4 + q);
+        av[q] = FLAT ? 0.0 : cen(v, col, t.k0 - 4 + q); ev[q] = FLAT ? 0.0 : cen(v, colN, t.k0 - 4 + q);
     }
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     double nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
-    double nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = cen(v, col, t.k0 + 2), nev = cen(v, colN, t.k0 + 2);
+    double nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = FLAT ? 0.0 : cen(v, col, t.k0 + 2), nev = FLAT ? 0.0 : cen(v, colN, t.k0 + 2);
     double ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0, ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : 0.0;
     double fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : 0.0;
     double fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : 0.0;
@@ -695,7 +717,8 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
         if (more) {
             tile_fetch(t, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, b + (size_t)(k + 1) * pl, pfb);
             nw5 = fac(k + 4); nb5 = cen(b, col, k + 4);
-            nau = cen(u, col, k + 3); neu = cen(u, colE, k + 3); nav = cen(v, col, k + 3); nev = cen(v, colN, k + 3);
+            nau = cen(u, col, k + 3); neu = cen(u, colE, k + 3);
+            if constexpr (!FLAT) { nav = cen(v, col, k + 3); nev = cen(v, colN, k + 3); }
             if (use_gm) { ngw = gm[eb + 3 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; ngb = gm[eb + (size_t)(k + 1) * pl + col]; }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -707,11 +730,14 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
             if (k > 0) {
                 double q7[7], c7[7];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : L(IW, q - 3, 0); c7[q] = (q == 3) ? w0 : L(IW, 0, q - 3); }
+                for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : L(IW, q - 3, 0); c7[q] = (q == 3 || FLAT) ? w0 : L(IW, 0, q - 3); }
                 const double fe = upw(zfS(eu, k, nz), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
                 const double fw = upw(zfS(au, k, nz), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
-                const double fn = upw(zfS(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-                const double fs = upw(zfS(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                double fn = 0.0, fs = 0.0;
+                if constexpr (!FLAT) {
+                    fn = upw(zfS(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+                    fs = upw(zfS(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                }
                 const double adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbw) * rdz;
                 const double vis = nu * ((((eu[3] - eu[2]) * rdz + (q7[4] - w0) * rdx) - ((au[3] - au[2]) * rdz + (w0 - q7[2]) * rdx)) * rdx
                                          + (((ev[3] - ev[2]) * rdz + (c7[4] - w0) * rdy) - ((av[3] - av[2]) * rdz + (w0 - c7[2]) * rdy)) * rdy
@@ -728,11 +754,14 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
             const double b0 = winb[2];
             double q7[7], c7[7];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : L(IB, q - 3, 0); c7[q] = (q == 3) ? b0 : L(IB, 0, q - 3); }
+            for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : L(IB, q - 3, 0); c7[q] = (q == 3 || FLAT) ? b0 : L(IB, 0, q - 3); }
             const double fe = upw(eu[3], left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
             const double fw = upw(au[3], left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
-            const double fn = upw(ev[3], left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-            const double fs = upw(av[3], left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            double fn = 0.0, fs = 0.0;
+            if constexpr (!FLAT) {
+                fn = upw(ev[3], left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+                fs = upw(av[3], left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            }
             double ft = 0.0, bup;
             if (k + 1 < nz) { ft = upw(winw[3], zfL(winb, k + 1, nz), zfR(winb, k + 1, nz)); bup = winb[3]; }
             else bup = ghost_hi(b0, g.min_b);
@@ -758,13 +787,13 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
 // read the same state buffer and write disjoint fields).  A kernel boundary on the dependent stream costs about 10 us on this
 // path whatever the kernels do (2.5 ms per env-step at B = 1, where all 234 launches are nearly empty); one launch fewer per
 // stage is worth more here than anything done inside the kernels.
-template <int TY3, int KT3, int NPF, int MAXT, int WAVES>
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false>
 __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_all(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
                                                    const double *nu_kappa, double dt, double gam, double zet, int store_g)
 {
     const int half = gridDim.x >> 1;                 // first half of the grid: (u, v); second half: (w, b), starting as the first drains
-    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half);
-    else tile_uv_body<TY3, KT3, NPF>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x);
+    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half);
+    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x);
 }
 
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------
@@ -1490,7 +1519,12 @@ __device__ __forceinline__ float obs_value2(const Out2D &P, int c, double x)
 // 2D outputs of one env per workgroup (256 threads; serial sums in index order: deterministic): channels b,u,w,pHY',pNHS as
 // float32 state and strided observations (rbc_sim2D_api.jl:102-129), Nusselt numbers on the state and on the sensor grid
 // (:142-163 with array_gradient, rbc_sim2D.jl:206-220), NaN flag.  phi = the last stage's potential (its mean removed).
-__global__ void __launch_bounds__(256) k2s_output(Geo3 g, const double *st, const double *phi, const double *nu_kappa, Out2D P, const uint8_t *mask)
+// When the tendencies used the un-split buoyancy (FLAT tile kernels) the projection's potential is phi + (gamma pHY'(stage) +
+// zeta pHY'(previous stage)) / (gamma + zeta) (see the note at the tile kernels): phyA / phyB are those two scans of the last
+// substep's stages 3 and 2, ca / cb their weights; phyA == nullptr (after a reset, and on the hydrostatic-split fallback kernels):
+// phi is pNHS itself.
+__global__ void __launch_bounds__(256) k2s_output(Geo3 g, const double *st, const double *phi, const double *nu_kappa, Out2D P, const uint8_t *mask,
+                                                  const double *phyA, const double *phyB, double ca, double cb)
 {
     extern __shared__ double sm2[];          // [nz] row means (state grid) | [nz] scratch | [256] reduction
     const int env = blockIdx.x, tid = threadIdx.x, nx = g.nx, nz = g.nz, nc = g.nc;
@@ -1498,6 +1532,8 @@ __global__ void __launch_bounds__(256) k2s_output(Geo3 g, const double *st, cons
     double *rowmean = sm2, *red = sm2 + 2 * nz;
     const double *sb = st + (size_t)env * g.env_stride;
     const double *b = sb, *u = sb + nc, *w = sb + 3 * (size_t)nc, *ph = phi + (size_t)env * nc;
+    const double *pa = phyA ? phyA + (size_t)env * nc : nullptr, *pb = phyA ? phyB + (size_t)env * nc : nullptr;
+    auto pnhs = [&](int c) -> double { return pa ? ph[c] - (ca * pa[c] + cb * pb[c]) : ph[c]; };
     const double kap = nu_kappa[2 * env + 1];
     auto block_sum = [&](double v) -> double {
         __syncthreads();
@@ -1510,7 +1546,7 @@ __global__ void __launch_bounds__(256) k2s_output(Geo3 g, const double *st, cons
     };
     // NaN flag + mean of phi
     double bad = 0.0, psum = 0.0;
-    for (int c = tid; c < nc; c += 256) { bad += (isnan(b[c]) || isnan(u[c]) || isnan(w[c])) ? 1.0 : 0.0; psum += ph[c]; }
+    for (int c = tid; c < nc; c += 256) { bad += (isnan(b[c]) || isnan(u[c]) || isnan(w[c])) ? 1.0 : 0.0; psum += pnhs(c); }
     bad = block_sum(bad);
     psum = block_sum(psum);
     if (tid == 0) P.flags[env] = bad > 0.0 ? 1 : 0;
@@ -1528,7 +1564,7 @@ __global__ void __launch_bounds__(256) k2s_output(Geo3 g, const double *st, cons
             const double above = (k == nz - 1) ? (bc + ((g.min_b - bc) / hz) * g.dz) : up;      // Value-BC halo above the top cell
             acc = acc - (0.5 * (bc + above)) * g.dz;
             up = bc;
-            const double vals[5] = {bc, u[c], w[c], acc, ph[c] - pmean};
+            const double vals[5] = {bc, u[c], w[c], acc, pnhs(c) - pmean};
             if (P.write_state)
                 for (int q = 0; q < 5; ++q) sbf[(size_t)q * nc + c] = (float)vals[q];
             if ((i % stx) == 0 && (k % stz) == 0) {
