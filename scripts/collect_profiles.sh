@@ -10,12 +10,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B2="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
-B3="python3 $ROOT/bench.py --dim 3 --steps 5 --warmup 2 --no-cpu-baseline"
+B3="python3 $ROOT/bench.py --dim 3 --steps 5 --warmup 2 --no-cpu-baseline --no-extra"
 run() { # name, extra rocprof args..., -- command
   local name=$1; shift
   echo "== $name" >&2
   timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv -d "$OUT/$name" "$@" > "$OUT/$name.log" 2>&1 || { echo "FAILED $name" >&2; tail -5 "$OUT/$name.log" >&2; return 1; }
 }
+ONLY=${2:-all}          # "3d": only the configs[4] passes
+if [ "$ONLY" != "3d" ]; then
 run trace --stats -- $B2 && grep '^{"metric"' "$OUT/trace.log" > "$OUT/bench_trace.log"
 run pmc_fetch --pmc FETCH_SIZE -- $B2
 run pmc_write --pmc WRITE_SIZE -- $B2
@@ -24,6 +26,7 @@ run pmc_sq2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_W
 BF="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --precision f32"
 run trace_f32 --stats -- $BF && grep '^{"metric"' "$OUT/trace_f32.log" > "$OUT/bench_trace_f32.log"
 run pmc_f32 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- $BF
+fi
 run trace3d --stats -- $B3 && grep '^{"metric"' "$OUT/trace3d.log" > "$OUT/bench_trace3d.log"
 run pmc_fetch3d --pmc FETCH_SIZE -- $B3
 run pmc_write3d --pmc WRITE_SIZE -- $B3
