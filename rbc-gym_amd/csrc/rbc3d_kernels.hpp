@@ -459,7 +459,9 @@ constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx 
 
 // FLAT (streaming-2D mode, ny = 1): a plane is ONE row of up to NXP values (no y halo), every y offset of a stencil read
 // aliases that row, and everything that involves v or a y-difference is compiled out (it is identically zero).
-template <int TY3, int KT3, int NXP = NXP3, bool FLAT = false>
+// NXC > 0: nx (and, NYC, ny) known at compile time -- the index arithmetic of the plane staging (idx / nx, the row wrap) turns
+// into multiplications by constants instead of 32-bit division sequences (about 17 VALU instructions each).
+template <int TY3, int KT3, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 struct TileGeo {
     static constexpr int ROWS3 = FLAT ? 1 : TY3 + 6;
     static constexpr int PLANE3 = ROWS3 * NXP;
@@ -468,7 +470,7 @@ struct TileGeo {
     int nx, ny, nz, pl, rows, plane, tiles, chunks, env, j0, k0, i, jl, j, tid, nthreads;
     __device__ __forceinline__ TileGeo(const Geo3 &g, int blk)
     {
-        nx = g.nx; ny = g.ny; nz = g.nz; pl = nx * ny; rows = ROWS3; plane = rows * nx;
+        nx = NXC ? NXC : g.nx; ny = NYC ? NYC : g.ny; nz = g.nz; pl = nx * ny; rows = ROWS3; plane = rows * nx;
         tiles = ny / TY3; chunks = nz / KT3;
         const int zc = blk % chunks, yt = (blk / chunks) % tiles;
         env = blk / (chunks * tiles); j0 = yt * TY3; k0 = zc * KT3;
@@ -506,13 +508,13 @@ __device__ __forceinline__ void tile_store(const TG &t, double *dst, const doubl
 // (u, v): blockDim = nx * TY3, B * (ny/TY3) * (nz/KT3) workgroups, LDS = 3 planes.  Two shapes are built:
 // 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
 // (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
-template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, double *nxt, double *gm,
                                              const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo<TY3, KT3, NXP, FLAT> t(g, blk);
-    constexpr int PLANE3 = TileGeo<TY3, KT3, NXP, FLAT>::PLANE3;
+    const TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC> t(g, blk);
+    constexpr int PLANE3 = TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PU = tile_sm, *PV = tile_sm + PLANE3, *PW = tile_sm + 2 * PLANE3;        // u(k), v(k), w(k+1)
     constexpr int IU = 0, IV = PLANE3, IW = 2 * PLANE3;
@@ -654,13 +656,13 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
 }
 
 // (w, b): same shape, LDS = 2 planes (w and b at the current level)
-template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, double *nxt, double *gm, const double *actT,
                                              const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
-    const TileGeo<TY3, KT3, NXP, FLAT> t(g, blk);
-    constexpr int PLANE3 = TileGeo<TY3, KT3, NXP, FLAT>::PLANE3;
+    const TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC> t(g, blk);
+    constexpr int PLANE3 = TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC>::PLANE3;
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     double *PW = tile_sm, *PB = tile_sm + PLANE3;
     constexpr int IW = 0, IB = PLANE3;
@@ -787,13 +789,13 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
 // read the same state buffer and write disjoint fields).  A kernel boundary on the dependent stream costs about 10 us on this
 // path whatever the kernels do (2.5 ms per env-step at B = 1, where all 234 launches are nearly empty); one launch fewer per
 // stage is worth more here than anything done inside the kernels.
-template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false>
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_all(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
                                                    const double *nu_kappa, double dt, double gam, double zet, int store_g)
 {
     const int half = gridDim.x >> 1;                 // first half of the grid: (u, v); second half: (w, b), starting as the first drains
-    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half);
-    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x);
+    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half);
+    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x);
 }
 
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------

@@ -385,3 +385,22 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
         for x, y in zip(f, outs[0][0]):
             assert rel_l2(x, y) < 1e-12
     assert len({float(x) for x in outs[0][1]}) == B             # 16 different envs, not copies
+
+
+def test_constant_grid_instantiations_agree_with_the_generic_ones(native, monkeypatch):
+    """configs[4]'s 48 x 48 planes run tile kernels instantiated with nx, ny as compile-time constants (index arithmetic by
+    multiplication); RBC_NO_CONST_GRID=1 selects the generic instantiations of the same bodies.  B = 8 takes the 16 x 16 tiles,
+    B = 2 the 16 x 4 ones."""
+    for B in (8, 2):
+        act = np.random.default_rng(B).uniform(-1, 1, (B, 8, 8)).astype(np.float32)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("RBC_NO_CONST_GRID", flag)
+            sim = native.NativeSim3D(batch=B, shape=(32, 48, 48), ra=1e4, random_kick=0.1)
+            sim.reset(np.arange(70, 70 + B, dtype=np.uint64))
+            assert sim.step(act)
+            outs.append(sim.get_fields())
+            sim.close()
+        monkeypatch.delenv("RBC_NO_CONST_GRID")
+        for x, y in zip(*outs):
+            assert np.isfinite(x).all() and rel_l2(x, y) < 1e-12
