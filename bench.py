@@ -17,7 +17,7 @@ scaling: 1024 envs per GPU).
 The JSON line carries, besides the contract's keys: `roofline` (SURVEY.md 8(d)'s algorithmic-bytes convention, with
 the PMC-measured HBM rate beside it), `roofline_valu` (the physically binding one: fp64 VALU issue), `copy_ceiling`
 (an on-box streaming-copy rate next to the 8 TB/s spec), `cpu_baseline` and `extra` (gym-API rate, configs[4] 3D,
-fp32 variant -- all measured in this run).
+fp32 variant, a 128x64 grid on the streaming 2D path -- all measured in this run).
 """
 import argparse
 import glob
@@ -396,6 +396,15 @@ def main():
                                              "roofline_frac_vs_36.86MB_per_env_step": alg32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "nan_envs": int(s32.get_flags().sum()), "mean_nusselt_state": float(np.mean(s32.get_nusselt()[0]))}
                     s32.close()
+                # a 2D grid the LDS-resident kernel has no instantiation for: the streaming path
+                s2 = _native.NativeSim(batch=B, device=local_rank, ra=args.ra, nx=128, nz=64, obs_nx=64, obs_nz=8)
+                s2.reset(sharding.env_seeds(1234, 0, B))
+                s2.step_dev(actions.data_ptr())
+                e2 = timed_loop(torch, dev, barrier, lambda n: s2.step_dev(actions.data_ptr() + ((1 + n) % (K + W)) * stride), 3)
+                extra["streaming_2d_128x64"] = {"value": B * 3 / e2, "unit": "env-steps/s", "ms_per_step": e2 / 3 * 1e3, "steps": 3, "warmup": 1,
+                                                "algorithmic_gbs": s2.algorithmic_bytes_per_env_step() * B * 3 / e2 / 1e9,
+                                                "nan_envs": int(s2.get_flags().sum()), "mean_nusselt_state": float(np.mean(s2.get_nusselt()[0]))}
+                s2.close()
             except Exception as e:                       # an extra must never take the contract line down with it
                 extra["error"] = f"{type(e).__name__}: {e}"
             out["extra"] = extra

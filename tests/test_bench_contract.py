@@ -89,3 +89,5 @@ def test_extra_keys_are_measured_in_the_same_run():
     c4 = x["config4_3d"]
     assert c4["nan_envs"] == 0 and c4["value"] > 0 and "32x48x48" in c4["config"]["workload"]
     assert d["roofline"]["on_box_copy_gbs"] == x["copy_ceiling"]["kernel_gbs"]
+    s2 = x["streaming_2d_128x64"]                           # a grid without an LDS-resident kernel: the streaming 2D path
+    assert s2["nan_envs"] == 0 and s2["value"] > 0 and 0.0 < s2["mean_nusselt_state"] < 6.0
