@@ -402,7 +402,9 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
 {
     rbc3_state *s = h->s3;
     const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
-    const bool standard = (nsub == h->nsub) && (dt == h->dt_solver_eff) && (dt_last == h->dt_last) && !h->no_graph;
+    // (the legacy default stream -- rbc_set_stream(h, hipStreamLegacy) -- cannot be captured: direct launches there)
+    const bool standard = (nsub == h->nsub) && (dt == h->dt_solver_eff) && (dt_last == h->dt_last) && !h->no_graph &&
+                          h->stream != nullptr && h->stream != hipStreamPerThread;      // (legacy = the null stream here, see rbc_set_stream)
     if (standard && actions_dev != h->d_actions)     // the graph reads the handle's own action buffer
         HIP3(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->B * (h->stream2d ? 1 : s->g.heaters) * s->g.heaters * sizeof(float),
                             hipMemcpyDeviceToDevice, h->stream));

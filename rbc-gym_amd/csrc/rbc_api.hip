@@ -375,11 +375,18 @@ int rbc_destroy(rbc_handle *h)
 int rbc_set_stream(rbc_handle *h, void *hip_stream)
 {
     if (int rc = check_handle(h)) return rc;
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    // hipStreamLegacy is kept as the null stream internally (the same stream; every HIP entry point takes it, which is not
+    // true of the (hipStream_t)1 alias: hipEventRecord / hipStreamWaitEvent fault on it in this runtime)
+    if (hip_stream == reinterpret_cast<void *>(hipStreamLegacy)) h->stream = nullptr;
+    else h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
     return RBC_OK;
 }
 
-void *rbc_get_stream(rbc_handle *h) { return h ? reinterpret_cast<void *>(h->stream) : nullptr; }
+void *rbc_get_stream(rbc_handle *h)
+{
+    if (!h) return nullptr;
+    return h->stream ? reinterpret_cast<void *>(h->stream) : reinterpret_cast<void *>(hipStreamLegacy);
+}
 
 int rbc_synchronize(rbc_handle *h)
 {

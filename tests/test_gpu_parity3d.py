@@ -404,3 +404,28 @@ def test_constant_grid_instantiations_agree_with_the_generic_ones(native, monkey
         monkeypatch.delenv("RBC_NO_CONST_GRID")
         for x, y in zip(*outs):
             assert np.isfinite(x).all() and rel_l2(x, y) < 1e-12
+
+
+def test_3d_env_groups_on_the_legacy_default_stream(native):
+    """rbc_set_stream(hipStreamLegacy): the env-step cannot be captured into a graph on that stream, so the group chains are
+    launched directly, forked from and joined into the legacy stream by events -- same results, and a torch kernel queued behind
+    the step on torch's default stream sees the finished state without an explicit synchronisation."""
+    torch = pytest.importorskip("torch")
+    B, shape = 16, (16, 32, 32)
+    kw = dict(batch=B, shape=shape, domain=DOMAIN, ra=5000.0, dt_control=0.05, dt_solver=0.01, random_kick=0.2)
+    ref, sim = native.NativeSim3D(**kw), native.NativeSim3D(**kw)
+    seeds = np.arange(5, 5 + B, dtype=np.uint64)
+    ref.reset(seeds); sim.reset(seeds)
+    sim._check(sim.lib.rbc_set_stream(sim.h, native.torch_stream_handle(torch.cuda.current_stream())))
+    from rbc_gym.vector import DeviceArray
+    nz, ny, nx = shape
+    view = torch.as_tensor(DeviceArray(sim.lib.rbc_dev_state(sim.h), (B, 4, nz, ny, nx), "<f4", sim), device="cuda")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    for step in range(2):
+        acts = (torch.rand((B, 8, 8), device="cuda", generator=gen) * 2 - 1).contiguous()      # produced on torch's stream, never synchronised
+        sim.step_dev(acts.data_ptr())
+        got = view.clone().cpu().numpy()                                                       # torch reads the view on the same stream
+        assert ref.step(acts.cpu().numpy())
+        assert np.array_equal(ref.get_state(), got)
+    sim._check(sim.lib.rbc_set_stream(sim.h, None))
+    sim.close(); ref.close()
