@@ -21,6 +21,8 @@ struct rbc3_state {
     int thr2d = 256;
     int rows2d = 0;                    // streaming-2D: rows (each packed with its mirror) per FFT workgroup, 0 = per-slab kernels
     size_t fft2d_lds = 0;
+    int fuse2d = 0;                    // streaming-2D: N1 of the one-kernel projection (k2s_project_fused), 0 = the separate kernels
+    size_t fuse2d_lds = 0;
     int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
     double tff = 1.0;
     // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" overrides them for the
@@ -45,7 +47,7 @@ namespace {
 
 void factor2(int n, int &n1, int &n2)
 {
-    if (n == 32 || n == 48 || n == 64 || n == 96 || n == 128) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8; the y pass is instantiated up to 64)
+    if (n == 32 || n == 48 || n == 64 || n == 96 || n == 128 || n == 192) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8; the y pass is instantiated up to 64)
     n1 = 1;
     for (int d = 1; d * d <= n; ++d)
         if (n % d == 0) n1 = d;
@@ -99,6 +101,16 @@ int create3d(rbc_handle *h)
         s->fft2d_lds = (size_t)(2 * s->rows2d * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
         HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_rhs_fft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft2d_lds));
         HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_ifft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft2d_lds));
+        // the whole projection as one kernel where an env's packed spectrum fits the LDS and nx = 8 * {4, 6, 8, 12, 16, 24}
+        const size_t need = ((size_t)(c.nz / 2) * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
+        const char *nf = std::getenv("RBC_NO_FUSE_PROJECT");
+        if (s->plan.nx2 == 8 && (s->plan.nx1 == 4 || s->plan.nx1 == 6 || s->plan.nx1 == 8 || s->plan.nx1 == 12 || s->plan.nx1 == 16 || s->plan.nx1 == 24) &&
+            c.nx <= 256 && need <= 150 * 1024 && !(nf && nf[0] == '1')) {
+            s->fuse2d = s->plan.nx1; s->fuse2d_lds = need;
+#define RBC_FUSE_ATTR(N1_) HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_project_fused<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            RBC_FUSE_ATTR(4) RBC_FUSE_ATTR(6) RBC_FUSE_ATTR(8) RBC_FUSE_ATTR(12) RBC_FUSE_ATTR(16) RBC_FUSE_ATTR(24)
+#undef RBC_FUSE_ATTR
+        }
     }
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
     const size_t B = h->B;
@@ -201,6 +213,13 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
     double *buf = s->st[which] + (size_t)q.e0 * g.env_stride;
     double *phi = s->phi + (size_t)q.e0 * g.nc;
     const uint8_t *mk = mask ? mask + q.e0 : nullptr;
+    if (s->fuse2d && g.nz % 2 == 0 && !h->no_pair) {
+#define RBC_FUSE_LAUNCH(N1_) if (s->fuse2d == N1_) hipLaunchKernelGGL(rbc3::k2s_project_fused<N1_>, dim3(B), dim3(256), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, 1);
+        RBC_FUSE_LAUNCH(4) RBC_FUSE_LAUNCH(6) RBC_FUSE_LAUNCH(8) RBC_FUSE_LAUNCH(12) RBC_FUSE_LAUNCH(16) RBC_FUSE_LAUNCH(24)
+#undef RBC_FUSE_LAUNCH
+        HIP3(hipGetLastError());
+        return RBC_OK;
+    }
     if (g.nz % 2 == 0 && !h->no_pair) {      // mirror slabs packed as one complex transform, z solve on the packed spectrum
         double2 *spec = s->spec + (size_t)q.e0 * (g.nz / 2) * pln, *jct = s->jct + (size_t)q.e0 * pln;
         const dim3 gm_ = grid_for((size_t)B * pln, 128);

@@ -1439,6 +1439,181 @@ __global__ void __launch_bounds__(256, 3) k2s_ifft_pair(Geo3 g, FftPlan pl, cons
     }
 }
 
+// ---- whole projection of a streaming-2D env in ONE kernel ------------------------------------------------------------------
+// Where the packed spectrum of an env (nz/2 rows of nx complex values) fits the LDS, one workgroup per env does what the five
+// launches above do without the spectrum or the potential ever travelling through memory: divergence of U*/dts of row k and of
+// its mirror row nz-1-k packed as one complex row -> row FFTs -> the z solve from both walls on the packed rows (the recurrences
+// of k3_thomas_pair_fwd / _bwd, one thread per mode, on LDS) -> inverse row FFTs -> u -= dts d(phi)/dx, w -= dts d(phi)/dz
+// (-> phi itself for the pNHS output when asked).  Reads u, w once and writes them once.
+// Row FFT, n = 8 N1, fully in place: forward = DFT-N1 over a at stride 8 (x index 8a + b2) with the twiddle W^(b2 k1), then
+// DFT-8 over the 8 contiguous values, which leaves mode m = k1 + N1 k2 at position 8 k1 + k2; the inverse undoes the two
+// steps in reverse order and ends in natural x order.  Nothing in spectral space needs the natural order: the pivots are looked
+// up by mode, the conjugate partner by its position.  Lanes run along rows (odd row stride: no bank conflicts).
+template <int N1>
+__device__ __forceinline__ void rowfft_inplace(double2 *A, int lines, int ls, const double2 *tw, int sign)
+{
+    if (sign < 0) {
+        for (int item = threadIdx.x; item < lines * 8; item += blockDim.x) {
+            const int b2 = item / lines, line = item - b2 * lines;
+            double2 *p = A + line * ls + b2;
+            double re[N1], im[N1];
+#pragma unroll
+            for (int a = 0; a < N1; ++a) { const double2 x = p[8 * a]; re[a] = x.x; im[a] = x.y; }
+            dftN<N1>(re, im);
+#pragma unroll
+            for (int k1 = 0; k1 < N1; ++k1) {
+                const double2 t = tw[b2 * k1];
+                p[8 * k1] = make_double2(re[k1] * t.x + im[k1] * t.y, im[k1] * t.x - re[k1] * t.y);      // times conj(t)
+            }
+        }
+        __syncthreads();
+        for (int item = threadIdx.x; item < lines * N1; item += blockDim.x) {
+            const int k1 = item / lines, line = item - k1 * lines;
+            double2 *p = A + line * ls + 8 * k1;
+            double re[8], im[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { const double2 x = p[b]; re[b] = x.x; im[b] = x.y; }
+            rbc::dft8(re, im);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) p[k2] = make_double2(re[k2], im[k2]);
+        }
+        __syncthreads();
+    } else {
+        for (int item = threadIdx.x; item < lines * N1; item += blockDim.x) {
+            const int k1 = item / lines, line = item - k1 * lines;
+            double2 *p = A + line * ls + 8 * k1;
+            double re[8], im[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) { const double2 x = p[k2]; re[k2] = x.x; im[k2] = x.y; }
+            rbc::dft8(im, re);
+#pragma unroll
+            for (int b2 = 0; b2 < 8; ++b2) {
+                const double2 t = tw[b2 * k1];
+                p[b2] = make_double2(re[b2] * t.x - im[b2] * t.y, re[b2] * t.y + im[b2] * t.x);          // times t
+            }
+        }
+        __syncthreads();
+        for (int item = threadIdx.x; item < lines * 8; item += blockDim.x) {
+            const int b2 = item / lines, line = item - b2 * lines;
+            double2 *p = A + line * ls + b2;
+            double re[N1], im[N1];
+#pragma unroll
+            for (int k1 = 0; k1 < N1; ++k1) { const double2 x = p[8 * k1]; re[k1] = x.x; im[k1] = x.y; }
+            dftN<N1>(im, re);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) p[8 * a] = make_double2(re[a], im[a]);
+        }
+        __syncthreads();
+    }
+}
+
+template <int N1>
+__global__ void __launch_bounds__(256) k2s_project_fused(Geo3 g, FftPlan pl, double *st, double *phi, const double *tab, double dts,
+                                                         const uint8_t *mask, int store_phi)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, nz = g.nz, half = nz / 2, ls = slab_row(nx), env = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    if (mask && !mask[env]) return;                               // masked reset: this env is not being projected
+    double2 *A = sm, *twx = sm + half * ls;
+    for (int t = tid; t < nx; t += nthr) twx[t] = pl.tw[t];
+    double *sb = st + (size_t)env * g.env_stride;
+    double *u = sb + g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double rdt = 1.0 / dts;
+    for (int idx = tid; idx < half * nx; idx += nthr) {
+        const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
+        const int ip = (i + 1 == nx) ? 0 : i + 1;
+        auto div = [&](int kk) -> double {
+            const size_t c = (size_t)kk * nx;
+            const double wt = (kk + 1 < nz) ? w[c + nx + i] : 0.0;
+            const double wb = (kk > 0) ? w[c + i] : 0.0;
+            return (u[c + ip] - u[c + i]) * g.rdx + (wt - wb) * g.rdz;
+        };
+        A[r * ls + i] = make_double2(div(r) * rdt, div(km) * rdt);
+    }
+    __syncthreads();
+    rowfft_inplace<N1>(A, half, ls, twx, -1);
+    // z solve, one thread per position p (mode m = k1 + N1 k2 at p = 8 k1 + k2)
+    {
+        const int p = tid;
+        const bool on = p < nx;
+        const int m = on ? (p >> 3) + N1 * (p & 7) : 0;
+        const int mc = (m == 0) ? 0 : nx - m, pc = 8 * (mc % N1) + mc / N1;          // conjugate partner and its position
+        const double o = g.rdz * g.rdz;
+        double yr = 0.0, yi = 0.0;
+        if (on) {
+            constexpr int BK = 8;
+            int k = 0;
+            for (; k + BK <= half; k += BK) {
+                double inv[BK];
+#pragma unroll
+                for (int q = 0; q < BK; ++q) inv[q] = tab[(size_t)(k + q) * nx + m];
+#pragma unroll
+                for (int q = 0; q < BK; ++q) {
+                    const double2 r = A[(k + q) * ls + p];
+                    yr = r.x * inv[q] - (inv[q] * o) * yr;
+                    yi = r.y * inv[q] - (inv[q] * o) * yi;
+                    A[(k + q) * ls + p] = make_double2(yr, yi);
+                }
+            }
+            for (; k < half; ++k) {
+                const double inv = tab[(size_t)k * nx + m];
+                const double2 r = A[k * ls + p];
+                yr = r.x * inv - (inv * o) * yr;
+                yi = r.y * inv - (inv * o) * yi;
+                A[k * ls + p] = make_double2(yr, yi);
+            }
+        }
+        __syncthreads();
+        double xr = 0.0, xi = 0.0;
+        if (on) {
+            const double2 P = A[(half - 1) * ls + p], Pc = A[(half - 1) * ls + pc];
+            const double c = tab[(size_t)(half - 1) * nx + m] * o;
+            if (m == 0) { xr = P.x; xi = 0.0; }                                       // singular mean mode: pin phi = 0 in row nz/2
+            else { const double jf = 1.0 / (1.0 - c * c); xr = jf * (P.x - c * Pc.y); xi = jf * (P.y - c * Pc.x); }
+        }
+        __syncthreads();                                                              // every junction value read before it is replaced
+        if (on) {
+            A[(half - 1) * ls + p] = make_double2(xr, xi);
+            constexpr int BK = 8;
+            int k = half - 2;
+            for (; k - BK + 1 >= 0; k -= BK) {
+                double cp[BK];
+#pragma unroll
+                for (int q = 0; q < BK; ++q) cp[q] = tab[(size_t)(k - q) * nx + m] * o;
+#pragma unroll
+                for (int q = 0; q < BK; ++q) {
+                    const double2 y = A[(k - q) * ls + p];
+                    xr = y.x - cp[q] * xr; xi = y.y - cp[q] * xi;
+                    A[(k - q) * ls + p] = make_double2(xr, xi);
+                }
+            }
+            for (; k >= 0; --k) {
+                const double cp = tab[(size_t)k * nx + m] * o;
+                const double2 y = A[k * ls + p];
+                xr = y.x - cp * xr; xi = y.y - cp * xi;
+                A[k * ls + p] = make_double2(xr, xi);
+            }
+        }
+        __syncthreads();
+    }
+    rowfft_inplace<N1>(A, half, ls, twx, +1);
+    // corrections (same operation order as k3_ifft_pair / k3_correct_w: differences of the normalised potentials)
+    const double sc = 1.0 / (double)nx;
+    double *ph = phi + (size_t)env * g.nc;
+    for (int idx = tid; idx < half * nx; idx += nthr) {
+        const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
+        const double2 c = A[r * ls + i], pw = A[r * ls + ((i == 0) ? nx - 1 : i - 1)];
+        u[(size_t)r * nx + i] -= (c.x * sc - pw.x * sc) * g.rdx * dts;
+        u[(size_t)km * nx + i] -= (c.y * sc - pw.y * sc) * g.rdx * dts;
+        if (store_phi) { ph[(size_t)r * nx + i] = c.x * sc; ph[(size_t)km * nx + i] = c.y * sc; }
+    }
+    auto phi_at = [&](int cell, int i) -> double { return (cell < half) ? A[cell * ls + i].x : A[(nz - 1 - cell) * ls + i].y; };
+    for (int idx = tid; idx < (nz - 1) * nx; idx += nthr) {
+        const int f = idx / nx + 1, i = idx - (f - 1) * nx;                           // face f between cells f-1 and f
+        w[(size_t)f * nx + i] -= (phi_at(f, i) * sc - phi_at(f - 1, i) * sc) * g.rdz * dts;
+    }
+}
+
 // bottom-plate temperature of every column: collate_actions_colin (rbc_sim2D.jl:87-133), same arithmetic as rbc2d_kernel
 __global__ void __launch_bounds__(128) k2s_wall(Geo3 g, const float *actions, double *wall, int zero_action, int B)
 {

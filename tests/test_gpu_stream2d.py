@@ -32,7 +32,10 @@ def oracle():
     dict(nx=256, nz=64, heaters=16, heater_limit=0.9, obs=(16, 32), dt_solver=0.01, dt_control=0.03, ra=1e5, lx=4 * np.pi),
     dict(nx=100, nz=40, heaters=7, heater_limit=0.6, obs=(5, 25), dt_solver=0.03, dt_control=0.08, ra=1e4),       # nx = 10 x 10: generic two-factor DFT
     dict(nx=72, nz=27, heaters=5, heater_limit=0.5, obs=(9, 36), dt_solver=0.03, dt_control=0.07, ra=5e3, lz=1.5, min_b=0.5, delta_b=2.0),  # odd nz: unpacked z solve, cell-per-thread tendencies
-], ids=["128x64", "192x32", "256x64", "100x40", "72x27"])
+    dict(nx=64, nz=40, heaters=8, heater_limit=0.75, obs=(8, 32), dt_solver=0.03, dt_control=0.07, ra=1e4),        # one-kernel projection, DFT-8 x 8 rows
+    dict(nx=48, nz=24, heaters=6, heater_limit=0.75, obs=(6, 24), dt_solver=0.03, dt_control=0.07, ra=3e3),        # DFT-6 x 8
+    dict(nx=32, nz=24, heaters=4, heater_limit=0.75, obs=(6, 16), dt_solver=0.03, dt_control=0.07, ra=3e3, lx=3.0),  # DFT-4 x 8
+], ids=["128x64", "192x32", "256x64", "100x40", "72x27", "64x40", "48x24", "32x24"])
 def test_streaming_2d_grids_match_oracle(native, oracle, cfg):
     """random reset, then two actuated control intervals (incl. a clipped last substep where dt_control is not a multiple
     of dt_solver): fields at round-off of the oracle, Nusselt numbers, float32 observations (all five channels)."""
@@ -78,6 +81,27 @@ def test_streaming_2d_grids_match_oracle(native, oracle, cfg):
             assert np.abs(st5[e][4] - so[4]).max() < 1e-5 * max(np.abs(so[4]).max(), 1e-3)    # pNHS: zero-mean potential of the last stage
     t, s = sim.get_info()
     assert np.allclose(t, 2 * cfg["dt_control"]) and np.all(s == 3)
+
+
+def test_one_kernel_projection_agrees_with_the_separate_kernels(native, monkeypatch):
+    """Where an env's packed spectrum fits the LDS the projection is one kernel (k2s_project_fused: 128x64, 192x32, ...);
+    RBC_NO_FUSE_PROJECT=1 runs the same grid on the separate kernels (row FFTs of several rows per workgroup, z sweeps,
+    inverse FFTs, corrections)."""
+    kw = dict(batch=3, nx=128, nz=64, obs_nx=64, obs_nz=8, dt_control=0.09, random_kick=0.05)
+    act = np.random.default_rng(3).uniform(-1, 1, (2, 3, 12)).astype(np.float32)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RBC_NO_FUSE_PROJECT", flag)
+        sim = native.NativeSim(**kw)
+        sim.reset(np.array([1, 2, 3], dtype=np.uint64))
+        for n in range(2):
+            assert sim.step(act[n])
+        outs.append((sim.get_fields(), sim.get_state(5), sim.get_nusselt()))
+        sim.close()
+    monkeypatch.delenv("RBC_NO_FUSE_PROJECT")
+    for x, y in zip(outs[0][0], outs[1][0]):
+        assert rel_l2(x, y) < 1e-11
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5) and np.allclose(outs[0][2], outs[1][2], rtol=1e-9)
 
 
 def test_streaming_2d_tendencies_and_heater_profile_match_oracle(native, oracle):
