@@ -320,7 +320,11 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
     else if (want("16x4", true) && tiles_fit(16, 4, 768)) shape = 3;
     else if (want("8x8", true) && tiles_fit(8, 8, 512)) shape = 4;
     // streaming-2D mode: the same bodies with one-row planes (FLAT), a workgroup = one row of nx threads marching 16 / 8 / 4 levels
-    if (h->stream2d && !h->no_tile && g.nx <= 256 && g.nz % 4 == 0) shape = (g.nz % 16 == 0) ? 5 : ((g.nz % 8 == 0) ? 6 : 7);
+    // (tall chunks while the launch keeps a few hundred workgroups; a small batch takes 4 levels: its step is a chain of short kernels)
+    if (h->stream2d && !h->no_tile && g.nx <= 256 && g.nz % 4 == 0) {
+        auto enough = [&](int kt) { return g.nz % kt == 0 && 2 * (size_t)B * (g.nz / kt) >= 256; };
+        shape = enough(16) ? 5 : (enough(8) ? 6 : 7);
+    }
     for (int n = 0; n < nsub; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;
         for (int ph = 0; ph < 3; ++ph) {
