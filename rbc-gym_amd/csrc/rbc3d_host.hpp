@@ -214,7 +214,8 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
     double *phi = s->phi + (size_t)q.e0 * g.nc;
     const uint8_t *mk = mask ? mask + q.e0 : nullptr;
     if (s->fuse2d && g.nz % 2 == 0 && !h->no_pair) {
-#define RBC_FUSE_LAUNCH(N1_) if (s->fuse2d == N1_) hipLaunchKernelGGL(rbc3::k2s_project_fused<N1_>, dim3(B), dim3(256), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, 1);
+        const int fthr = 512;             // measured: 256 -> 512 threads +12 % (more loads in flight around the LDS phases); 768 / 1024: no better
+#define RBC_FUSE_LAUNCH(N1_) if (s->fuse2d == N1_) hipLaunchKernelGGL(rbc3::k2s_project_fused<N1_>, dim3(B), dim3(fthr), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, 1);
         RBC_FUSE_LAUNCH(4) RBC_FUSE_LAUNCH(6) RBC_FUSE_LAUNCH(8) RBC_FUSE_LAUNCH(12) RBC_FUSE_LAUNCH(16) RBC_FUSE_LAUNCH(24)
 #undef RBC_FUSE_LAUNCH
         HIP3(hipGetLastError());

@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void rowfft_inplace(double2 *A, int lines, int ls, co
 }
 
 template <int N1>
-__global__ void __launch_bounds__(256) k2s_project_fused(Geo3 g, FftPlan pl, double *st, double *phi, const double *tab, double dts,
+__global__ void __launch_bounds__(512) k2s_project_fused(Geo3 g, FftPlan pl, double *st, double *phi, const double *tab, double dts,
                                                          const uint8_t *mask, int store_phi)
 {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
