@@ -204,7 +204,8 @@ inline dim3 grid_for(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / b
 inline rbc3_grp whole_batch(const rbc_handle *h) { return rbc3_grp{0, h->B, h->stream}; }
 
 // exact projection of state buffer `which` (0/1) of the group's envs with stage step dts (mask: device pointer [B] or null)
-int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask)
+// (want_phi = false: the caller does not need the potential itself afterwards -- only the one-kernel streaming-2D projection can skip its store)
+int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask, bool want_phi = true)
 {
     rbc3_state *s = h->s3;
     const rbc3::Geo3 &g = s->g;
@@ -215,7 +216,7 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
     const uint8_t *mk = mask ? mask + q.e0 : nullptr;
     if (s->fuse2d && g.nz % 2 == 0 && !h->no_pair) {
         const int fthr = 512;             // measured: 256 -> 512 threads +12 % (more loads in flight around the LDS phases); 768 / 1024: no better
-#define RBC_FUSE_LAUNCH(N1_) if (s->fuse2d == N1_) hipLaunchKernelGGL(rbc3::k2s_project_fused<N1_>, dim3(B), dim3(fthr), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, 1);
+#define RBC_FUSE_LAUNCH(N1_) if (s->fuse2d == N1_) hipLaunchKernelGGL(rbc3::k2s_project_fused<N1_>, dim3(B), dim3(fthr), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, want_phi ? 1 : 0);
         RBC_FUSE_LAUNCH(4) RBC_FUSE_LAUNCH(6) RBC_FUSE_LAUNCH(8) RBC_FUSE_LAUNCH(12) RBC_FUSE_LAUNCH(16) RBC_FUSE_LAUNCH(24)
 #undef RBC_FUSE_LAUNCH
         HIP3(hipGetLastError());
@@ -383,7 +384,8 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
                 hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
                 hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
             }
-            if (int rc = project3d(h, q, which ^ 1, (gam[ph] + zet[ph]) * d, nullptr)) return rc;
+            // the potential is an output (pNHS) only after the last stage of the control interval
+            if (int rc = project3d(h, q, which ^ 1, (gam[ph] + zet[ph]) * d, nullptr, n == nsub - 1 && ph == 2)) return rc;
             which ^= 1;
         }
     }
