@@ -21,6 +21,10 @@ struct rbc3_state {
     int thr2d = 256;
     int rows2d = 0;                    // streaming-2D: rows (each packed with its mirror) per FFT workgroup, 0 = per-slab kernels
     size_t fft2d_lds = 0;
+    int ip2d = 0;                      // streaming-2D: N1 of the in-place separate kernels (k2s_*_ip), spectrum in position order
+    size_t ip2d_lds = 0;
+    double *tab_perm = nullptr;        // the pivot table with its columns in position order, and the conjugate partner of every position
+    int *partner = nullptr;
     int fuse2d = 0;                    // streaming-2D: N1 of the one-kernel projection (k2s_project_fused), 0 = the separate kernels
     size_t fuse2d_lds = 0;
     int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
@@ -47,7 +51,7 @@ namespace {
 
 void factor2(int n, int &n1, int &n2)
 {
-    if (n == 32 || n == 48 || n == 64 || n == 96 || n == 128 || n == 192) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8; the y pass is instantiated up to 64)
+    if (n == 32 || n == 48 || n == 64 || n == 96 || n == 128 || n == 192 || n == 256) { n1 = n / 8; n2 = 8; return; }   // register-blocked fast path (N1 x 8; the y pass is instantiated up to 64)
     n1 = 1;
     for (int d = 1; d * d <= n; ++d)
         if (n % d == 0) n1 = d;
@@ -104,12 +108,23 @@ int create3d(rbc_handle *h)
         // the whole projection as one kernel where an env's packed spectrum fits the LDS and nx = 8 * {4, 6, 8, 12, 16, 24}
         const size_t need = ((size_t)(c.nz / 2) * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
         const char *nf = std::getenv("RBC_NO_FUSE_PROJECT");
-        if (s->plan.nx2 == 8 && (s->plan.nx1 == 4 || s->plan.nx1 == 6 || s->plan.nx1 == 8 || s->plan.nx1 == 12 || s->plan.nx1 == 16 || s->plan.nx1 == 24) &&
-            c.nx <= 256 && need <= 150 * 1024 && !(nf && nf[0] == '1')) {
-            s->fuse2d = s->plan.nx1; s->fuse2d_lds = need;
+        const int n1 = s->plan.nx1;
+        const bool fast_rows = s->plan.nx2 == 8 && (n1 == 4 || n1 == 6 || n1 == 8 || n1 == 12 || n1 == 16 || n1 == 24 || n1 == 32) && c.nx <= 256;
+        if (fast_rows && need <= 150 * 1024 && !(nf && nf[0] == '1')) {
+            s->fuse2d = n1; s->fuse2d_lds = need;
 #define RBC_FUSE_ATTR(N1_) HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_project_fused<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            RBC_FUSE_ATTR(4) RBC_FUSE_ATTR(6) RBC_FUSE_ATTR(8) RBC_FUSE_ATTR(12) RBC_FUSE_ATTR(16) RBC_FUSE_ATTR(24)
+            RBC_FUSE_ATTR(4) RBC_FUSE_ATTR(6) RBC_FUSE_ATTR(8) RBC_FUSE_ATTR(12) RBC_FUSE_ATTR(16) RBC_FUSE_ATTR(24) RBC_FUSE_ATTR(32)
 #undef RBC_FUSE_ATTR
+        } else if (fast_rows) {          // the spectrum of an env does not fit: separate kernels with the in-place row FFT
+            int Rr = 16;
+            while (Rr > 1 && (c.nz / 2) % Rr != 0) Rr /= 2;
+            s->ip2d = n1; s->rows2d = Rr;
+            s->ip2d_lds = ((size_t)Rr * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
+#define RBC_IP_ATTR(N1_)                                                                                                                 \
+            HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_rhs_fft_pair_ip<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->ip2d_lds)); \
+            HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_ifft_pair_ip<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->ip2d_lds));
+            RBC_IP_ATTR(4) RBC_IP_ATTR(6) RBC_IP_ATTR(8) RBC_IP_ATTR(12) RBC_IP_ATTR(16) RBC_IP_ATTR(24) RBC_IP_ATTR(32)
+#undef RBC_IP_ATTR
         }
     }
     if (s->fft_lds > 160 * 1024) return fail(RBC_ERR_INVALID, "3D horizontal slab too large for the LDS FFT (nx*ny <= ~5000)");
@@ -152,6 +167,20 @@ int create3d(rbc_handle *h)
             }
         HIP3(hipMalloc(&s->tab, tab.size() * sizeof(double)));
         HIP3(hipMemcpy(s->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (s->ip2d) {                   // position p = 8 k1 + k2 holds mode m = k1 + N1 k2 (rowfft_inplace)
+            const int N1 = s->ip2d, nx = c.nx;
+            std::vector<double> tp((size_t)c.nz * nx);
+            std::vector<int> pa(nx);
+            for (int p = 0; p < nx; ++p) {
+                const int m = (p >> 3) + N1 * (p & 7), mc = (m == 0) ? 0 : nx - m;
+                pa[p] = 8 * (mc % N1) + mc / N1;
+                for (int k = 0; k < c.nz; ++k) tp[(size_t)k * nx + p] = tab[(size_t)k * nx + m];
+            }
+            HIP3(hipMalloc(&s->tab_perm, tp.size() * sizeof(double)));
+            HIP3(hipMemcpy(s->tab_perm, tp.data(), tp.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIP3(hipMalloc(&s->partner, pa.size() * sizeof(int)));
+            HIP3(hipMemcpy(s->partner, pa.data(), pa.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
     }
     {   // RBC_3D_GROUPS=n overrides the default (4 groups of >= 4 envs for 3D handles; streaming-2D batches are large: 1)
         int want = h->stream2d ? 1 : 4;
@@ -192,7 +221,7 @@ void destroy3d(rbc_handle *h)
     for (hipStream_t q : s->gstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : s->gdone) if (e) (void)hipEventDestroy(e);
     if (s->gstart) (void)hipEventDestroy(s->gstart);
-    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phy2, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
+    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phy2, s->tab_perm, s->partner, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -218,6 +247,7 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
         const int fthr = 512;             // measured: 256 -> 512 threads +12 % (more loads in flight around the LDS phases); 768 / 1024: no better
 #define RBC_FUSE_LAUNCH(N1_) if (s->fuse2d == N1_) hipLaunchKernelGGL(rbc3::k2s_project_fused<N1_>, dim3(B), dim3(fthr), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, want_phi ? 1 : 0);
         RBC_FUSE_LAUNCH(4) RBC_FUSE_LAUNCH(6) RBC_FUSE_LAUNCH(8) RBC_FUSE_LAUNCH(12) RBC_FUSE_LAUNCH(16) RBC_FUSE_LAUNCH(24)
+        if (s->fuse2d == 32) hipLaunchKernelGGL(rbc3::k2s_project_fused<32>, dim3(B), dim3(256), s->fuse2d_lds, q.st, g, s->plan, buf, phi, s->tab, dts, mk, want_phi ? 1 : 0);
 #undef RBC_FUSE_LAUNCH
         HIP3(hipGetLastError());
         return RBC_OK;
@@ -226,17 +256,27 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
         double2 *spec = s->spec + (size_t)q.e0 * (g.nz / 2) * pln, *jct = s->jct + (size_t)q.e0 * pln;
         const dim3 gm_ = grid_for((size_t)B * pln, 128);
         const int thr2d = s->thr2d;
+        const double *tabz = s->ip2d ? s->tab_perm : s->tab;            // z-sweep tables in the order of the spectrum
+        const int *partner = s->ip2d ? s->partner : nullptr;
+#define RBC_IP_RHS(N1_) if (s->ip2d == N1_) hipLaunchKernelGGL(rbc3::k2s_rhs_fft_pair_ip<N1_>, dim3(B * (g.nz / 2 / s->rows2d)), dim3(256), s->ip2d_lds, q.st, g, s->plan, buf, spec, dts, s->rows2d);
+#define RBC_IP_INV(N1_) if (s->ip2d == N1_) hipLaunchKernelGGL(rbc3::k2s_ifft_pair_ip<N1_>, dim3(B * (g.nz / 2 / s->rows2d)), dim3(256), s->ip2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
+        if (s->ip2d) { RBC_IP_RHS(4) RBC_IP_RHS(6) RBC_IP_RHS(8) RBC_IP_RHS(12) RBC_IP_RHS(16) RBC_IP_RHS(24) RBC_IP_RHS(32) }
+        else
         if (s->rows2d) hipLaunchKernelGGL(rbc3::k2s_rhs_fft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, buf, spec, dts, s->rows2d);
         else hipLaunchKernelGGL(rbc3::k3_rhs_fft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, buf, spec, dts);
-        if (g.nz == 32 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<16>, gm_, dim3(128), 0, q.st, g, spec, s->tab, B);
-        else if (g.nz == 16 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<8>, gm_, dim3(128), 0, q.st, g, spec, s->tab, B);
+        if (g.nz == 32 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<16>, gm_, dim3(128), 0, q.st, g, spec, tabz, B, partner);
+        else if (g.nz == 16 && !h->no_fuse_z) hipLaunchKernelGGL(rbc3::k3_thomas_pair_fused<8>, gm_, dim3(128), 0, q.st, g, spec, tabz, B, partner);
         else {
-            hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, q.st, g, spec, jct, s->tab, B);
-            hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, q.st, g, spec, jct, s->tab, B);
+            hipLaunchKernelGGL(rbc3::k3_thomas_pair_fwd, gm_, dim3(128), 0, q.st, g, spec, jct, tabz, B);
+            hipLaunchKernelGGL(rbc3::k3_thomas_pair_bwd, gm_, dim3(128), 0, q.st, g, spec, jct, tabz, B, partner);
         }
+        if (s->ip2d) { RBC_IP_INV(4) RBC_IP_INV(6) RBC_IP_INV(8) RBC_IP_INV(12) RBC_IP_INV(16) RBC_IP_INV(24) RBC_IP_INV(32) }
+        else
         if (s->rows2d) hipLaunchKernelGGL(rbc3::k2s_ifft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
         else hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
         hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
+#undef RBC_IP_RHS
+#undef RBC_IP_INV
         HIP3(hipGetLastError());
         return RBC_OK;
     }

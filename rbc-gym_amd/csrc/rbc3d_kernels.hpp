@@ -879,9 +879,30 @@ __device__ __forceinline__ void dft6(double *re, double *im)
         re[(3 + 4 * d) % 6] = dr[d]; im[(3 + 4 * d) % 6] = di[d];
     }
 }
+// DFT-32 as two DFT-16 (even / odd samples) + one radix-2 butterfly with W32^k
+__device__ __forceinline__ void dft32(double *re, double *im)
+{
+    double er[16], ei[16], orr[16], oi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { er[j] = re[2 * j]; ei[j] = im[2 * j]; orr[j] = re[2 * j + 1]; oi[j] = im[2 * j + 1]; }
+    rbc::dft16(er, ei);
+    rbc::dft16(orr, oi);
+    // cos(2 pi k / 32), k = 0..8 (the rest by symmetry); W32^k = c[k] - i s[k]
+    constexpr double c32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708, 0.70710678118654752440,
+                               0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double wr = (k <= 8) ? c32[k] : -c32[16 - k], wi = -((k <= 8) ? c32[8 - k] : c32[k - 8]);
+        const double tr = orr[k] * wr - oi[k] * wi, ti = orr[k] * wi + oi[k] * wr;
+        re[k] = er[k] + tr; im[k] = ei[k] + ti;
+        re[k + 16] = er[k] - tr; im[k + 16] = ei[k] - ti;
+    }
+}
+
 template <int N1> __device__ __forceinline__ void dftN(double *re, double *im)
 {
-    static_assert(N1 == 4 || N1 == 6 || N1 == 8 || N1 == 12 || N1 == 16 || N1 == 24, "register-blocked slab FFT: n = 8 * {4, 6, 8, 12, 16, 24}");
+    static_assert(N1 == 4 || N1 == 6 || N1 == 8 || N1 == 12 || N1 == 16 || N1 == 24 || N1 == 32, "register-blocked slab FFT: n = 8 * {4, 6, 8, 12, 16, 24, 32}");
+    if (N1 == 32) { dft32(re, im); return; }
     if (N1 == 4) dft4(re, im);
     else if (N1 == 6) dft6(re, im);
     else if (N1 == 8) rbc::dft8(re, im);
@@ -1122,14 +1143,16 @@ __global__ void k3_thomas_pair_fwd(Geo3 g, double2 *spec, double2 *jct, const do
 }
 
 // junction with the conjugate mode, then back-substitution outward
-__global__ void k3_thomas_pair_bwd(Geo3 g, double2 *spec, const double2 *jct, const double *tab, int B)
+// partner != nullptr: the spectrum is in another order than the natural one (in-place row FFTs of the streaming-2D mode); tab is
+// then permuted likewise and partner[p] is the position of the conjugate mode
+__global__ void k3_thomas_pair_bwd(Geo3 g, double2 *spec, const double2 *jct, const double *tab, int B, const int *partner = nullptr)
 {
     const int nx = g.nx, ny = g.ny, pln = nx * ny, half = g.nz / 2;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pln * B) return;
     const int env = t / pln, mn = t - env * pln;
     const int n = mn / nx, m = mn - n * nx;
-    const int mp = ((n == 0) ? 0 : ny - n) * nx + ((m == 0) ? 0 : nx - m);     // mode (-kx, -ky)
+    const int mp = partner ? partner[mn] : ((n == 0) ? 0 : ny - n) * nx + ((m == 0) ? 0 : nx - m);     // mode (-kx, -ky)
     double2 *s = spec + (size_t)env * half * pln + mn;
     const double o = g.rdz * g.rdz;
     const double2 P = jct[(size_t)env * pln + mn], Pc = jct[(size_t)env * pln + mp];
@@ -1163,14 +1186,14 @@ __global__ void k3_thomas_pair_bwd(Geo3 g, double2 *spec, const double2 *jct, co
 // (2 x HALF complex values) in registers between the sweeps.  Threads of the partner modes exit at once (whole waves, except
 // in the two self-conjugate rows).  Same recurrences in the same order as k3_thomas_pair_fwd / _bwd: bitwise the same result.
 template <int HALF>
-__global__ void __launch_bounds__(128) k3_thomas_pair_fused(Geo3 g, double2 *spec, const double *tab, int B)
+__global__ void __launch_bounds__(128) k3_thomas_pair_fused(Geo3 g, double2 *spec, const double *tab, int B, const int *partner = nullptr)
 {
     const int nx = g.nx, ny = g.ny, pln = nx * ny;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pln * B) return;
     const int env = t / pln, mn = t - env * pln;
     const int n = mn / nx, m = mn - n * nx;
-    const int mp = ((n == 0) ? 0 : ny - n) * nx + ((m == 0) ? 0 : nx - m);     // mode (-kx, -ky)
+    const int mp = partner ? partner[mn] : ((n == 0) ? 0 : ny - n) * nx + ((m == 0) ? 0 : nx - m);     // mode (-kx, -ky)
     if (mp < mn) return;                                                       // the partner's thread does this pair
     const bool self = (mp == mn);
     double2 *sa = spec + (size_t)env * HALF * pln + mn, *sb = spec + (size_t)env * HALF * pln + mp;
@@ -1507,8 +1530,64 @@ __device__ __forceinline__ void rowfft_inplace(double2 *A, int lines, int ls, co
     }
 }
 
+// The separate rhs / inverse kernels with the in-place row FFT (grids whose packed spectrum does not fit one workgroup's LDS:
+// 192x128, 256x128, ...): R row pairs per workgroup, half the LDS of the out-of-place version, spectrum in position order
+// (mode k1 + N1 k2 at 8 k1 + k2; the z-sweep kernels get the pivot table permuted alike and a partner table).
 template <int N1>
-__global__ void __launch_bounds__(512) k2s_project_fused(Geo3 g, FftPlan pl, double *st, double *phi, const double *tab, double dts,
+__global__ void __launch_bounds__(256) k2s_rhs_fft_pair_ip(Geo3 g, FftPlan pl, const double *st, double2 *spec, double dts, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, nz = g.nz, half = nz / 2, ls = slab_row(nx), per = half / R;
+    const int env = blockIdx.x / per, k0 = (blockIdx.x - env * per) * R;
+    double2 *A = sm, *twx = sm + R * ls;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) twx[t] = pl.tw[t];
+    const double *sb = st + (size_t)env * g.env_stride;
+    const double *u = sb + g.nc, *w = sb + 3 * (size_t)g.nc;
+    const double rdt = 1.0 / dts;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) {
+        const int r = idx / nx, i = idx - r * nx, k = k0 + r, km = nz - 1 - k;
+        const int ip = (i + 1 == nx) ? 0 : i + 1;
+        auto div = [&](int kk) -> double {
+            const size_t c = (size_t)kk * nx;
+            const double wt = (kk + 1 < nz) ? w[c + nx + i] : 0.0;
+            const double wb = (kk > 0) ? w[c + i] : 0.0;
+            return (u[c + ip] - u[c + i]) * g.rdx + (wt - wb) * g.rdz;
+        };
+        A[r * ls + i] = make_double2(div(k) * rdt, div(km) * rdt);
+    }
+    __syncthreads();
+    rowfft_inplace<N1>(A, R, ls, twx, -1);
+    double2 *o = spec + ((size_t)env * half + k0) * nx;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) { const int r = idx / nx, i = idx - r * nx; o[idx] = A[r * ls + i]; }
+}
+
+template <int N1>
+__global__ void __launch_bounds__(256) k2s_ifft_pair_ip(Geo3 g, FftPlan pl, const double2 *spec, double *phi, double *st, double dts, const uint8_t *mask, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int nx = g.nx, nz = g.nz, half = nz / 2, ls = slab_row(nx), per = half / R;
+    const int env = blockIdx.x / per, k0 = (blockIdx.x - env * per) * R;
+    if (mask && !mask[env]) return;
+    double2 *A = sm, *twx = sm + R * ls;
+    for (int t = threadIdx.x; t < nx; t += blockDim.x) twx[t] = pl.tw[t];
+    const double2 *in = spec + ((size_t)env * half + k0) * nx;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) { const int r = idx / nx, i = idx - r * nx; A[r * ls + i] = in[idx]; }
+    __syncthreads();
+    rowfft_inplace<N1>(A, R, ls, twx, +1);
+    const double sc = 1.0 / (double)nx;
+    double *sb = st + (size_t)env * g.env_stride;
+    double *ph = phi + (size_t)env * g.nc, *u = sb + g.nc;
+    for (int idx = threadIdx.x; idx < R * nx; idx += blockDim.x) {
+        const int r = idx / nx, i = idx - r * nx, k = k0 + r, km = nz - 1 - k;
+        const double2 c = A[r * ls + i], pw = A[r * ls + ((i == 0) ? nx - 1 : i - 1)];
+        ph[(size_t)k * nx + i] = c.x * sc; ph[(size_t)km * nx + i] = c.y * sc;
+        u[(size_t)k * nx + i] -= (c.x * sc - pw.x * sc) * g.rdx * dts;
+        u[(size_t)km * nx + i] -= (c.y * sc - pw.y * sc) * g.rdx * dts;
+    }
+}
+
+template <int N1>
+__global__ void __launch_bounds__(N1 >= 32 ? 256 : 512) k2s_project_fused(Geo3 g, FftPlan pl, double *st, double *phi, const double *tab, double dts,
                                                          const uint8_t *mask, int store_phi)
 {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];

@@ -35,7 +35,9 @@ def oracle():
     dict(nx=64, nz=40, heaters=8, heater_limit=0.75, obs=(8, 32), dt_solver=0.03, dt_control=0.07, ra=1e4),        # one-kernel projection, DFT-8 x 8 rows
     dict(nx=48, nz=24, heaters=6, heater_limit=0.75, obs=(6, 24), dt_solver=0.03, dt_control=0.07, ra=3e3),        # DFT-6 x 8
     dict(nx=32, nz=24, heaters=4, heater_limit=0.75, obs=(6, 16), dt_solver=0.03, dt_control=0.07, ra=3e3, lx=3.0),  # DFT-4 x 8
-], ids=["128x64", "192x32", "256x64", "100x40", "72x27", "64x40", "48x24", "32x24"])
+    dict(nx=192, nz=128, heaters=12, heater_limit=0.75, obs=(8, 48), dt_solver=0.01, dt_control=0.025, ra=1e5),     # spectrum too large for one workgroup: in-place separate kernels (DFT-24 x 8)
+    dict(nx=256, nz=128, heaters=12, heater_limit=0.75, obs=(8, 64), dt_solver=0.01, dt_control=0.025, ra=1e6),     # DFT-32 x 8
+], ids=["128x64", "192x32", "256x64", "100x40", "72x27", "64x40", "48x24", "32x24", "192x128", "256x128"])
 def test_streaming_2d_grids_match_oracle(native, oracle, cfg):
     """random reset, then two actuated control intervals (incl. a clipped last substep where dt_control is not a multiple
     of dt_solver): fields at round-off of the oracle, Nusselt numbers, float32 observations (all five channels)."""
