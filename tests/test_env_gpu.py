@@ -576,3 +576,19 @@ def test_precision_kwarg_selects_the_float32_variant(gym):
     o, _ = e32.reset(seed=11)
     assert np.array_equal(o, v32.reset(seed=11)[0][0])
     v64.close(); v32.close(); e32.close()
+
+
+def test_sharded_3d_env_with_env_groups_and_graphs(gym):
+    """Two 3D handles of 16 envs on one device (`devices=[0, 0]`), each cutting its batch into four env groups on their own
+    streams and capturing its env-step into a graph from its own driver thread: bitwise the single-handle env."""
+    kw = dict(num_envs=32, heater_duration=0.05, dt_solver=0.01, state_shape=[16, 32, 32])
+    a = gym.make_vec(ID3, **kw)
+    b = gym.make_vec(ID3, devices=[0, 0], **kw)
+    oa, _ = a.reset(seed=3); ob, _ = b.reset(seed=3)
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(0)
+    for n in range(4):
+        act = rng.uniform(-1, 1, (32, 8, 8)).astype(np.float32)
+        oa, ra, *_ = a.step(act); ob, rb, *_ = b.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb), n
+    a.close(); b.close()
