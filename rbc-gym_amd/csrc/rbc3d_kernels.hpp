@@ -2,12 +2,16 @@
 //
 // Replaces `step_simulation`/`initialize_simulation` of src/rbc_gym/sim/rbc_sim3D_api.jl (77-101,
 // 17-72) for a batch of envs.  A 3D env (32x48x48: 2.4 MB of fp64 state) does not fit one CU's LDS,
-// so unlike the 2D kernel the state lives in HBM/L2 (32 envs = 75 MB, resident in the 256 MB
-// Infinity Cache) and every RK3 stage is a short sequence of launches:
-//   hydrostatic scan -> tendency kernels (LDS-tiled; z-marching and cell-per-thread fallbacks) writing U*
-//   into the other state buffer -> per-z-slab 2D FFT in LDS -> per-(kx,ky) tridiagonal sweep -> inverse
-//   FFT -> projection.
+// so unlike the 2D kernel the state lives in HBM/L2 and every RK3 stage is a short sequence of launches
+// (rbc3d_host.hpp: advance3d / project3d):
+//   k3_tile_all (LDS-tiled tendencies of (u,v) and (w,b), U* into the other state buffer; z-marching and
+//   cell-per-thread kernels as fallbacks for other grid shapes) -> k3_rhs_fft_pair (divergence of two mirror
+//   slabs as one complex 2D FFT in LDS) -> k3_thomas_pair_fused (z solve per (kx,ky) from both walls on the
+//   packed spectrum) -> k3_ifft_pair (inverse FFT + u, v correction) -> k3_correct_w.
+// The batch is cut into env groups whose chains run on separate streams (one captured graph per env-step).
 // Same discretisation as the 2D kernel; layouts [k][j][i].
+// The second half of the file is the streaming-2D mode: 2D grids without an LDS-resident kernel on these
+// kernels with ny = 1 (FLAT tiles, k2s_* kernels, the one-kernel projection k2s_project_fused).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
