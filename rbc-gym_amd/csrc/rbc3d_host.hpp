@@ -383,19 +383,24 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
                 const size_t pb = (size_t)(TY + 6) * rbc3::NXP3 * sizeof(double);                                                        \
                 hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
             }
-            // (48, 48) horizontal planes -- configs[4] -- have instantiations with nx, ny as compile-time constants: the index
-            // arithmetic of the plane staging becomes multiplications (a third fewer VALU instructions in the kernel, +4-5 % env-steps/s)
-#define RBC_TILE_LAUNCH48(TY, KT, THR, WAVES)                                                                                            \
+            // (48, 48) horizontal planes -- configs[4] --, the registry default (32, 32) and the flowstats experiment's (64, 64) have
+            // instantiations with nx, ny as compile-time constants: the index arithmetic of the plane staging becomes multiplications
+            // (a third fewer VALU instructions in the kernel, +4-5 % env-steps/s)
+#define RBC_TILE_LAUNCHC(TY, KT, THR, WAVES, NXC_, NYC_)                                                                                 \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * rbc3::NXP3 * sizeof(double);                                                        \
-                hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES, rbc3::NXP3, false, 48, 48>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
+                hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES, rbc3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
             }
-            const bool c48 = (g.nx == 48 && g.ny == 48 && !no_nxc);
-            if (shape == 1 && c48) RBC_TILE_LAUNCH48(16, 16, 768, 3)
-            else if (shape == 2 && c48) RBC_TILE_LAUNCH48(16, 8, 768, 3)
-            else if (shape == 3 && c48) RBC_TILE_LAUNCH48(16, 4, 768, 3)
-#undef RBC_TILE_LAUNCH48
+            const bool c48 = (g.nx == 48 && g.ny == 48 && !no_nxc), c32 = (g.nx == 32 && g.ny == 32 && !no_nxc), c64 = (g.nx == 64 && g.ny == 64 && !no_nxc);
+            if (shape == 1 && c48) RBC_TILE_LAUNCHC(16, 16, 768, 3, 48, 48)
+            else if (shape == 2 && c48) RBC_TILE_LAUNCHC(16, 8, 768, 3, 48, 48)
+            else if (shape == 3 && c48) RBC_TILE_LAUNCHC(16, 4, 768, 3, 48, 48)
+            else if (shape == 1 && c32) RBC_TILE_LAUNCHC(16, 16, 768, 3, 32, 32)
+            else if (shape == 2 && c32) RBC_TILE_LAUNCHC(16, 8, 768, 3, 32, 32)
+            else if (shape == 3 && c32) RBC_TILE_LAUNCHC(16, 4, 768, 3, 32, 32)
+            else if (shape == 4 && c64) RBC_TILE_LAUNCHC(8, 8, 512, 2, 64, 64)
+#undef RBC_TILE_LAUNCHC
             else if (shape == 1) RBC_TILE_LAUNCH(16, 16, 768, 3)
             else if (shape == 2) RBC_TILE_LAUNCH(16, 8, 768, 3)
             else if (shape == 3) RBC_TILE_LAUNCH(16, 4, 768, 3)
