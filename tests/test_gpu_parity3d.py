@@ -391,12 +391,12 @@ def test_constant_grid_instantiations_agree_with_the_generic_ones(native, monkey
     """configs[4]'s 48 x 48 planes run tile kernels instantiated with nx, ny as compile-time constants (index arithmetic by
     multiplication); RBC_NO_CONST_GRID=1 selects the generic instantiations of the same bodies.  B = 8 takes the 16 x 16 tiles,
     B = 2 the 16 x 4 ones."""
-    for B in (8, 2):
+    for B, shape in ((8, (32, 48, 48)), (2, (32, 48, 48)), (16, (16, 32, 32)), (2, (16, 64, 64))):      # + the registry default and the flowstats planes
         act = np.random.default_rng(B).uniform(-1, 1, (B, 8, 8)).astype(np.float32)
         outs = []
         for flag in ("0", "1"):
             monkeypatch.setenv("RBC_NO_CONST_GRID", flag)
-            sim = native.NativeSim3D(batch=B, shape=(32, 48, 48), ra=1e4, random_kick=0.1)
+            sim = native.NativeSim3D(batch=B, shape=shape, ra=1e4, random_kick=0.1)
             sim.reset(np.arange(70, 70 + B, dtype=np.uint64))
             assert sim.step(act)
             outs.append(sim.get_fields())
