@@ -248,34 +248,39 @@ def test_flowstats_pin_p4(native):
 
 
 def test_flowstats_series_pin(native, golden_dir):
-    """Time-resolved pin on the reference's own data: Nu(t) of the 14 zero-action runs behind experiments/flowstats
-    (tests/golden/flowstats_ref_series.npz, extracted from flowstats_ra.pkl by a non-executing opcode walk,
-    tests/golden/extract_flowstats.py) against an 8-member ensemble per Rayleigh number on the native 3D stepper at the
-    reference's protocol (32x64x64, heater_duration 0.25, dt_solver 0.005; flowstats_ra.py:27-36).  The reference is ONE
-    realisation per Ra drawn from Julia's RNG, so every check is statistical: z = (ref - ensemble mean) / member std.
+    """Time-resolved pin on the reference's own data: the four per-step series of the 14 zero-action runs behind
+    experiments/flowstats (flowstats_ra.py:55-66; tests/golden/flowstats_ref_series.npz, extracted from flowstats_ra.pkl by a
+    non-executing opcode walk, tests/golden/extract_flowstats.py) against 8-member ensembles per Rayleigh number on the
+    native 3D stepper at the reference's protocol (32x64x64, heater_duration 0.25, dt_solver 0.005; flowstats_ra.py:27-36).
+    The reference is ONE realisation per Ra drawn from Julia's RNG, so every check is statistical.
 
       (a) steps 1-3, all 14 Ra: the decay of the random kick and the first growth, |z| < 4.5 (recorded 16-member run:
           max 2.6 of 42).  Nu-1 scales with kick^2: this pins the IC amplitude and the first control interval.
-      (b) overshoot: the step of the first Nusselt maximum equals the ensemble's within one step (Ra >= 750).
-      (c) clock: the time map t_ref = a + F n that carries the ensemble mean onto the reference's pre-peak curve has
-          F = 0.982 +- 0.001 (mean over Ra >= 4000 of the recorded run): the reference's series runs 1.8 % slower than
-          the documented protocol integrated exactly -- 49 instead of 50 solver steps per env.step reproduce it
-          (F = 1.001 +- 0.001, tests/golden/flowstats3d_series_experiments.json), halving dt_solver or replacing RK3 by three
-          Euler stages does not move it.  The reference's sources integrate to stop_time (rbc_sim3D_api.jl:63,88-89), which is
-          what this build does; the assertion below brackets the KNOWN factor so that a clock change of one solver step in
-          either direction (F = 1.00 or 0.96) fails.  DESIGN.md section 4 has the full account.
-      (d) the peak Nusselt number within 6 %.
-    """
+      (b) overshoot: the step of the first Nusselt maximum equals the ensemble's within one step (Ra >= 750); peak within 6 %.
+      (c) the BUILD's clock, with no reference data: the ensemble's increments of log(Nu-1) equal those of the linear theory
+          of the discretisation (tests/linear_theory3d.py: 50 RK3 substeps of 0.02 per env-step, no free parameter) within
+          1 % per env-step and 0.4 % on average (recorded 16-member run: 0.05-0.3 %).
+      (d) the SHAPE of the reference's deviation, tau(n) of scripts/flowstats3d_tau.py on all four series: a straight line
+          tau(n) = 1 + 0.98 (n - 1) -- the first env-step agrees with the documented clock, every later one carries the growth
+          of 49 solver steps instead of 50, from Nu-1 ~ 1e-4 on (not an amplitude / resolution effect) and at every Ra >= 4000
+          alike (recorded: slope 0.9825 +- 0.0015, tau(1) = 1.007 +- 0.010; velocity maxima 0.976 +- 0.008, the same line).
+      (e) the explanation run: 50 solver steps in the first env-step, 49 in every later one -> slope 1.000 +- 0.003 and the
+          reference inside the ensemble through growth, overshoot and decay (rms z 1.0 over 30 env-steps at Ra <= 512000;
+          documented clock: 1.8).
+    The reference's sources integrate every env-step to stop_time (rbc_sim3D_api.jl:63,88-89), i.e. 50 solver steps, and
+    that is what this build ships; DESIGN.md section 4 has the full account of what (d) and (e) can and cannot decide."""
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "scripts"))
+    for p in (os.path.join(os.path.dirname(golden_dir), "..", "scripts"), os.path.dirname(golden_dir)):
+        sys.path.insert(0, p)
     from flowstats3d_series import run_series
-    from flowstats3d_compare import time_map
+    from flowstats3d_tau import analyse, summary
+    from linear_theory3d import LinearRBC3D
     ref = np.load(os.path.join(golden_dir, "flowstats_ref_series.npz"))
     ras, seeds, steps = ref["ra"], 8, 45
     out = run_series(ras, seeds, steps, seed0=4242)
     nu = out["nusselt"]                                              # [ra, member, step]
     infl = np.sqrt(1.0 + 1.0 / seeds)
-    worst, Fs = 0.0, []
+    worst = 0.0
     for i, ra in enumerate(ras):
         m, s = (nu[i] - 1).mean(0), (nu[i] - 1).std(0, ddof=1)
         r = ref["nusselt"][i, :steps] - 1
@@ -289,14 +294,63 @@ def test_flowstats_series_pin(native, golden_dir):
         assert am.max() < steps - 1, (ra, am)
         assert abs(ar - np.median(am)) <= 1, (ra, ar, am)             # (b)
         pk = nu[i].max(1)
-        assert abs(ref["nusselt"][i, :steps].max() - pk.mean()) < 0.06 * pk.mean(), (ra, pk.mean())       # (d)
-        if ra >= 4000:
-            npk = int(np.argmax(m))
-            F, a, rms = time_map(np.log(m), np.log(r), npk - 1)
-            assert rms < 0.03 and 0.955 < F < 1.005 and abs(a) < 0.11, (ra, F, a, rms)
-            Fs.append(F)
-    assert 0.972 < np.mean(Fs) < 0.992, Fs                            # (c): recorded 0.9822 +- 0.0012
-    print(f"flowstats series pin: max |z| over steps 1-3 = {worst:.2f}, mean pre-peak time factor F = {np.mean(Fs):.4f}")
+        assert abs(ref["nusselt"][i, :steps].max() - pk.mean()) < 0.06 * pk.mean(), (ra, pk.mean())
+    ratios = []
+    for ra in (8000.0, 16000.0):                                      # (c)
+        i = int(np.argmin(np.abs(ras - ra)))
+        th = np.diff(np.log(LinearRBC3D(ra).nusselt_series(8, 0.02, 50)))[2:7]
+        en = np.diff(np.log(nu[i][:, :8] - 1).mean(0))[2:7]
+        assert np.all(np.abs(en / th - 1.0) < 0.01), (ra, en / th)
+        ratios.append(en / th)
+    assert abs(np.mean(ratios) - 1.0) < 0.004, ratios
+    base = summary(analyse(ref, out))                                # (d)
+    sn = base["nusselt"]
+    assert 0.976 < sn["slope_mean"] < 0.989 and sn["slope_sem"] < 0.003 and abs(sn["tau1_mean"] - 1.0) < 0.05, sn
+    vel = np.mean([base[k]["slope_mean"] for k in ("umax", "vmax", "wmax")])
+    assert 0.93 < vel < 1.01, base
+    out49 = run_series(ras, seeds, 30, seed0=4242, dt_control=0.245, lead_substeps=1)      # (e)
+    s49 = summary(analyse(ref, out49))["nusselt"]
+    assert abs(s49["slope_mean"] - 1.0) < 0.008, s49
+    def zscores(o):
+        zs = []
+        for i, ra in enumerate(ras):
+            if 4000 <= ra <= 512000:
+                la = np.log(o["nusselt"][i][:, :30] - 1)
+                zs.append((np.log(ref["nusselt"][i, :30] - 1) - la.mean(0)) / (la.std(0, ddof=1) * infl))
+        return np.array(zs)
+    z50, z49 = zscores(out), zscores(out49)
+    rms50, rms49 = float(np.sqrt((z50 ** 2).mean())), float(np.sqrt((z49 ** 2).mean()))
+    # 8 members: z is t-distributed with 7 degrees of freedom, so the bar is on the rms and the 3-sigma fraction, not on the
+    # maximum (recorded with 16 members: rms 1.02, all 240 below 2.6 -- against rms 1.84, 11 % beyond 3 for the documented clock)
+    assert rms49 < 1.35 and (np.abs(z49) < 3).mean() > 0.96 and rms50 > 1.25 * rms49, (rms49, rms50)
+    print(f"flowstats series pin: max |z| steps 1-3 = {worst:.2f}; build/theory increments {np.mean(ratios):.4f}; tau slope {sn['slope_mean']:.4f} "
+          f"+- {sn['slope_sem']:.4f}, tau(1) {sn['tau1_mean']:.3f}; velocity slopes {vel:.3f}; 50-then-49: slope {s49['slope_mean']:.4f}, rms z {rms49:.2f} (documented clock {rms50:.2f})")
+
+
+def test_roundoff_sized_extra_substep_changes_nothing(native):
+    """Oceananigans' `run!` clips its last step to stop_time - t; in double precision the clock often ends an env-step one
+    ulp short and a 51st solver step of ~1e-16 follows (Simulations/run.jl `aligned_time_step`; rbc_sim3D_api.jl:88).  Such
+    a step divides a round-off divergence by a round-off dt in the pressure solve; here it is shown to leave the state where
+    it was (relative change < 1e-12) and the next env-step on the same trajectory -- it cannot be the missing 2 %."""
+    B = 2
+    zero = np.zeros((B, 8, 8), np.float32)
+    sims = [native.NativeSim3D(batch=B, shape=(16, 32, 32), ra=20000.0, dt_control=0.25, dt_solver=0.005) for _ in range(2)]
+    for sim in sims:
+        sim.reset(np.arange(B, dtype=np.uint64) + 5)
+    for n in range(6):
+        for k, sim in enumerate(sims):
+            assert sim.step(zero)
+            if k == 1:
+                before = sim.get_fields()
+                sim.debug_substeps(zero, 1, 1.1e-16)
+                after = sim.get_fields()
+                for x, y in zip(before, after):
+                    assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(x).max())
+    fa, fb = sims[0].get_fields(), sims[1].get_fields()
+    for x, y in zip(fa, fb):
+        assert np.linalg.norm(x - y) <= 1e-10 * max(np.linalg.norm(x), 1e-30)
+    for sim in sims:
+        sim.close()
 
 
 @pytest.mark.parametrize("shape", [SHAPE, (16, 32, 32)], ids=["tiles-8x8", "tiles-16x4"])
