@@ -72,36 +72,110 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(dim=2, envs=64, nsteps=None, budget_s=12.0):
+def _cpu_quota():
+    """CPU time this process may use per wall second, in cores, from the cgroup (v2 cpu.max, v1 cfs quota); None = unlimited."""
+    try:
+        rel = "/"
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2]
+        best = None
+        path = os.path.join("/sys/fs/cgroup", rel.lstrip("/"))
+        while True:                                   # the tightest limit on the way up to the root
+            f = os.path.join(path, "cpu.max")
+            if os.path.exists(f):
+                q, per = open(f).read().split()[:2]
+                if q != "max":
+                    c = float(q) / float(per)
+                    best = c if best is None else min(best, c)
+            if os.path.realpath(path) == "/sys/fs/cgroup":
+                break
+            path = os.path.dirname(path)
+        if best is not None:
+            return best
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def _physical_cores(allowed):
+    """distinct (package, core) pairs among the logical CPUs this process may run on (SMT siblings count once)"""
+    seen = set()
+    for c in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology"
+            seen.add((open(f"{base}/physical_package_id").read().strip(), open(f"{base}/core_id").read().strip()))
+        except OSError:
+            seen.add(("?", c))
+    return len(seen)
+
+
+def cpu_baseline(dim=2, envs=64, budget_s=12.0):
+    """The C oracle on the host cores this process REALLY gets: worker count = min(affinity, cgroup quota, physical cores,
+    envs); when no quota is published and the affinity mask is wider than 32 CPUs, a short scaling probe (1 / 16 / 64 /
+    all workers, one env-step each) picks the widest pool that still scales.  Reports the single-worker rate beside the
+    total, so `cores_effective` = total / single-worker rate says how much compute was actually obtained."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py
     oracle_py.build_oracle()
     try:
-        cores = len(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    nproc = os.cpu_count() or cores
-    envs = max(envs, cores) if dim == 2 else cores
+        allowed = list(range(os.cpu_count() or 1))
+    nproc = os.cpu_count() or len(allowed)
+    quota = _cpu_quota()
+    phys = _physical_cores(allowed)
+    limit = min(len(allowed), phys, envs if dim == 2 else 32)
+    if quota is not None:
+        limit = max(1, min(limit, int(quota + 0.5)))
     ctx = mp.get_context("fork")
-    shards = [list(range(r, envs, cores)) for r in range(cores)]
     t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        if nsteps is None:            # calibrate: one env-step of every env, then as many as the time budget allows
-            cal = max(pool.map(_cpu_worker, [(s, 1, dim) for s in shards]))
-            nsteps = int(max(1, min(200, budget_s / max(cal, 1e-3))))
-        per = pool.map(_cpu_worker, [(s, nsteps, dim) for s in shards])
+    _cpu_worker(([0], 1, dim))                                # warm (page cache, tables, clocks) ...
+    single = _cpu_worker(([0], 2, dim)) / 2.0                 # ... then one env on one core: the per-core yardstick
+    probe = {}
+
+    def rate(workers, nsteps):
+        n_env = max(envs, workers) if dim == 2 else workers
+        shards = [list(range(r, n_env, workers)) for r in range(workers)]
+        with ctx.Pool(workers) as pool:
+            per = pool.map(_cpu_worker, [(s, nsteps, dim) for s in shards])
+        return n_env, per
+
+    workers = limit
+    if quota is None and len(allowed) > 32:                   # no published quota on a wide mask: measure where scaling stops
+        for wk in sorted({1, 16, min(64, limit), limit}):
+            n_env, per = rate(wk, 1)
+            probe[wk] = n_env / max(per)
+        workers = max(probe, key=lambda k: probe[k])
+    n_env, cal = rate(workers, 1)
+    spent = time.perf_counter() - t0
+    nsteps = int(max(1, min(200, (budget_s - spent) / max(max(cal), 1e-3))))
+    n_env, per = rate(workers, nsteps)
     wall = time.perf_counter() - t0
     stepping = max(per)
+    total = n_env * nsteps / stepping
+    single_rate = 1.0 / single
     what = ("64x96, Ra=1e4, 50 RK3 substeps, random ICs seeds 1234+i, U(-1,1) actions" if dim == 2 else
             "32x48x48, Ra=1e4, 13 RK3 substeps, random ICs seeds 1234+i, U(-1,1) 8x8 actions")
-    return {"value": envs * nsteps / stepping, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "per_core": envs * nsteps / sum(per), "nproc": nproc, "cpu_model": _cpu_model(),
-            "sample": f"{envs} envs spread over {cores} worker processes (all cores this process may use; nproc={nproc}) x {nsteps} "
-                      f"env-steps of the bench workload ({what}) on the C oracle (oracle/, readable scalar C, direct O(N^2) "
-                      f"DFT in its Poisson solve: a deliberately plain port, a baseline and not a tuned CPU code); "
-                      f"{stepping:.1f} s stepping, {wall:.1f} s wall incl. calibration. Julia reference unavailable on this box "
-                      f"(README.md:62 publishes 0.12 s/step at 34 substeps on one Apple-silicon core = 5.7 env-steps/s at 50)"}
+    return {"value": total, "unit": "env-steps/s", "cores": workers, "kind": "port",
+            "per_core": total / workers, "single_worker": single_rate, "cores_effective": total / single_rate,
+            "nproc": nproc, "affinity": len(allowed), "physical_cores": phys, "cgroup_cpu_quota": quota,
+            "scaling_probe": {str(k): v for k, v in probe.items()} or None, "cpu_model": _cpu_model(),
+            "sample": f"{n_env} envs spread over {workers} worker processes (min of affinity {len(allowed)}, cgroup quota {quota}, "
+                      f"physical cores {phys}, envs; nproc={nproc}) x {nsteps} env-steps of the bench workload ({what}) on the C oracle "
+                      f"(oracle/, readable scalar C, direct O(N^2) DFT in its Poisson solve: a deliberately plain port, a baseline and not "
+                      f"a tuned CPU code); one worker alone: {single_rate:.2f} env-steps/s; {stepping:.1f} s stepping, {wall:.1f} s wall incl. "
+                      f"calibration. Julia reference unavailable on this box (README.md:62 publishes 0.12 s/step at 34 substeps on one "
+                      f"Apple-silicon core = 5.7 env-steps/s at 50)"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -169,6 +243,7 @@ def run_3d(ctx, B, K, W, ra):
     ms = sim.profile_read(K)
     nan_envs = int(sim.get_flags().sum())
     nu = sim.get_nusselt()
+    rank_elapsed, rank_nan = sharding.gather_run(elapsed, nan_envs, device=ctx["red_dev"], dist=ctx["dist"] if world > 1 else None)
     elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=ctx["red_dev"], dist=ctx["dist"] if world > 1 else None)
     alg = sim.algorithmic_bytes_per_env_step() * B
     avg = float(np.mean(ms)) if len(ms) else float("nan")
@@ -189,7 +264,8 @@ def run_3d(ctx, B, K, W, ra):
                      "kernel": "rbc3 stage sequence x 39 per env-step (one 'launch' = one env-step of the batch)",
                      "kernel_ms_avg": avg, "algorithmic_bytes_per_launch": alg,
                      "note": "algorithmic bytes = 10*F*C*s per substep (F=4, C=73728, s=8) x 13 x batch"},
-        "nan_envs": nan_total, "mean_nusselt": float(np.mean(nu))}
+        "nan_envs": nan_total, "mean_nusselt": float(np.mean(nu)),
+        "per_rank": {"ms_per_step": [e / K * 1e3 for e in rank_elapsed], "nan_envs": rank_nan}}
 
 
 def gym_api_rate(ctx, B, steps, info_state):
@@ -208,6 +284,64 @@ def gym_api_rate(ctx, B, steps, info_state):
     dt = time.perf_counter() - t0
     venv.close()
     return B * steps / dt
+
+
+def ra_sweep_extra(ctx, B, spin, K):
+    """configs[3] on one GPU: contiguous thirds of the batch at Ra = 1e4 / 1e5 / 1e6, fixed dt = 0.03 as in the reference
+    (substep / CFL stress).  `spin` untimed env-steps first, so that the high-Ra thirds are convecting
+    (and at their advective CFL) when the K timed ones run."""
+    torch, np, _native, sharding = ctx["torch"], ctx["np"], ctx["_native"], ctx["sharding"]
+    dev = ctx["dev"]
+    ras = (1e4, 1e5, 1e6)
+    ra_env = np.array([ras[min(2, e * 3 // B)] for e in range(B)])
+    sim = _native.NativeSim(batch=B, device=ctx["local_rank"], ra=1e4)
+    sim.set_rayleigh(ra_env)
+    sim.reset(sharding.env_seeds(1234, 0, B))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    acts = (torch.rand((8, B, 12), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).contiguous()
+    torch.cuda.synchronize(dev)
+    stride = B * 12 * 4
+    for n in range(spin):
+        sim.step_dev(acts.data_ptr() + (n % 8) * stride)
+    e = timed_loop(torch, dev, ctx["barrier"], lambda n: sim.step_dev(acts.data_ptr() + (n % 8) * stride), K)
+    flags = sim.get_flags()
+    nus, _ = sim.get_nusselt()
+    out = {"value": B * K / e, "unit": "env-steps/s", "ms_per_step": e / K * 1e3, "steps": K, "spin_up_steps": spin, "batch": B,
+           "rayleigh_numbers": list(ras), "dt_solver": 0.03,
+           "nan_envs_per_ra": {f"{r:g}": int(flags[ra_env == r].sum()) for r in ras},
+           "mean_nusselt_state_per_ra": {f"{r:g}": float(np.nanmean(nus[ra_env == r])) for r in ras},
+           "note": "BASELINE.json configs[3] per GPU: batch split into contiguous thirds, one Rayleigh number each, random U(-1,1) actions"}
+    sim.close()
+    return out
+
+
+def steady_ckpt_extra(ctx, B, K):
+    """SURVEY.md 8(d) C2 'steady' variant: the reference's stored Ra=1e4 steady states (tests/golden/ckpt2d_ra10000.npz: three
+    episodes of data/checkpoints/train/ckpt_ra10000.h5) tiled across the batch, zero action: throughput, and how far the
+    kinetic energy and the Nusselt number move per env-step (the reference's 40 episodes scatter by 1e-6 / 3.5e-6 relative)."""
+    torch, np, _native = ctx["torch"], ctx["np"], ctx["_native"]
+    ck = np.load(os.path.join(ROOT, "tests", "golden", "ckpt2d_ra10000.npz"))
+    n_ep = ck["b"].shape[0]
+    idx = np.arange(B) % n_ep
+    sim = _native.NativeSim(batch=B, device=ctx["local_rank"], ra=1e4)
+    sim.reset_from_arrays(ck["b"][idx], ck["u"][idx], ck["w"][idx])
+
+    def ke():
+        b, u, w = sim.get_fields()
+        return 0.5 * ((u ** 2).mean(axis=(1, 2)) + (w[:, :-1] ** 2).mean(axis=(1, 2)))
+    ke0, nu0 = ke(), sim.get_nusselt()[0].copy()
+    zero = torch.zeros((B, 12), device=ctx["dev"], dtype=torch.float32)
+    torch.cuda.synchronize(ctx["dev"])
+    e = timed_loop(torch, ctx["dev"], ctx["barrier"], lambda n: sim.step_dev(zero.data_ptr()), K)
+    ke1, nu1 = ke(), sim.get_nusselt()[0]
+    out = {"value": B * K / e, "unit": "env-steps/s", "ms_per_step": e / K * 1e3, "steps": K, "batch": B, "episodes_tiled": int(n_ep),
+           "kinetic_energy": float(ke1.mean()), "reference_kinetic_energy": 0.0983448,
+           "max_rel_ke_drift_per_env_step": float(np.abs(ke1 / ke0 - 1).max() / K),
+           "max_rel_nusselt_drift_per_env_step": float(np.abs(nu1 / nu0 - 1).max() / K),
+           "nusselt_state": float(nu1.mean()), "nan_envs": int(sim.get_flags().sum())}
+    sim.close()
+    return out
 
 
 def main():
@@ -233,7 +367,19 @@ def main():
         raise SystemExit("--gpus must be >= 1")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))                     # the ranks print the line; this process never touches the GPU
+        # the ranks print the line; this process never touches the GPU.  The CPU baseline runs HERE, before the ranks exist
+        # (they would compete for the host cores), and travels to rank 0 through a file.
+        tmp = None
+        if not args.no_cpu_baseline:
+            import tempfile
+            fd, tmp = tempfile.mkstemp(prefix="rbc_cpu_baseline_", suffix=".json")
+            with os.fdopen(fd, "w") as f:
+                json.dump(cpu_baseline(dim=args.dim), f)
+            os.environ["RBC_BENCH_CPU_BASELINE_FILE"] = tmp
+        rc = self_launch(args)
+        if tmp and os.path.exists(tmp):
+            os.unlink(tmp)
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,6 +389,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(dim=args.dim)
+    elif rank == 0 and os.environ.get("RBC_BENCH_CPU_BASELINE_FILE"):      # measured by the self-launching parent
+        try:
+            cpu = json.load(open(os.environ["RBC_BENCH_CPU_BASELINE_FILE"]))
+        except (OSError, ValueError):
+            cpu = None
 
     import numpy as np
     import torch
@@ -306,6 +457,7 @@ def main():
     flags = sim.get_flags()
     nan_envs = int(flags.sum())
     nus, _ = sim.get_nusselt()
+    rank_elapsed, rank_nan = sharding.gather_run(elapsed, nan_envs, device=red_dev, dist=dist if world > 1 else None)
     elapsed, nan_total = sharding.reduce_run(elapsed, nan_envs, device=red_dev, dist=dist if world > 1 else None)
     alg_bytes = sim.algorithmic_bytes_per_env_step() * B          # per launch
     sim.close()
@@ -365,6 +517,8 @@ def main():
             "roofline_valu": valu,
             "cpu_baseline": cpu,
             "nan_envs": nan_total,
+            "per_rank": {"ms_per_step": [e / K * 1e3 for e in rank_elapsed], "nan_envs": rank_nan,
+                         "note": "value uses the slowest rank (max over ranks); a straggler GPU shows here"},
             "ra_sweep": ({"values": [float(x) for x in args.ra_sweep.split(",")],
                           "rank0_nan_envs_per_ra": {f"{r:g}": int(flags[ra_env == r].sum()) for r in sorted(set(ra_env))},
                           "rank0_mean_nusselt_per_ra": {f"{r:g}": float(np.mean(nus[ra_env == r])) for r in sorted(set(ra_env))}}
@@ -394,8 +548,13 @@ def main():
                     alg32 = s32.algorithmic_bytes_per_env_step() * B
                     extra["fp32_variant"] = {"value": B * k32 / e32, "unit": "env-steps/s", "ms_per_step": e32 / k32 * 1e3, "kernel_ms_avg": ms32,
                                              "roofline_frac_vs_36.86MB_per_env_step": alg32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "nan_envs": int(s32.get_flags().sum()), "mean_nusselt_state": float(np.mean(s32.get_nusselt()[0]))}
+                                             "nan_envs": int(s32.get_flags().sum()), "mean_nusselt_state": float(np.mean(s32.get_nusselt()[0])),
+                                             "mean_nusselt_state_note": f"after 2 + {k32} env-steps from the same seeds (the f64 line's value is after "
+                                                                        f"{W} + {K}): a different time of the transient, not a parity signal -- parity of "
+                                                                        "the float32 variant is tests/test_gpu_parity.py"}
                     s32.close()
+                extra["ra_sweep_config3"] = ra_sweep_extra(ctx, B, 50, 5)
+                extra["steady_ckpt"] = steady_ckpt_extra(ctx, B, 5)
                 # a 2D grid the LDS-resident kernel has no instantiation for: the streaming path
                 s2 = _native.NativeSim(batch=B, device=local_rank, ra=args.ra, nx=128, nz=64, obs_nx=64, obs_nz=8)
                 s2.reset(sharding.env_seeds(1234, 0, B))

@@ -39,6 +39,12 @@ struct rbc3_state {
     // own stream (envs are independent), so that one group's latency-bound phases (single-round FFT launches, kernel tails)
     // overlap another group's tendency kernels.  1 = the whole batch on the handle's stream.
     int groups = 1;
+    // time slices: the batch is cut into `slices` contiguous ranges that run their WHOLE env-step one after the other (each
+    // slice on its `groups` chains), so that the working set of what is in flight -- two state buffers, G^-, potential,
+    // spectrum of the slice's envs -- stays inside the 256 MB Infinity Cache: a streaming copy whose working set fits runs at
+    // 7.1 TB/s on this chip, 5.2 TB/s from HBM (scripts/mall_probe.py).  1 = the whole batch at once (the default: slicing
+    // measured slower, see create3d).
+    int slices = 1;
     std::vector<hipStream_t> gstream;
     std::vector<hipEvent_t> gdone;
     hipEvent_t gstart = nullptr;
@@ -57,6 +63,12 @@ void factor2(int n, int &n1, int &n2)
         if (n % d == 0) n1 = d;
     n2 = n / n1;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per-kernel PROCESS state: setting it to one handle's need would lower it under
+// another live handle on a larger grid (whose next launch then fails with hipErrorInvalidValue).  It is a ceiling, not a
+// reservation -- occupancy follows the size a launch actually asks for -- so every kernel gets the CU's whole LDS once.
+constexpr int RBC_LDS_CEILING = 160 * 1024;
+#define RBC_LDS_ATTR(fn) HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, RBC_LDS_CEILING))
 
 #define HIP3(expr)                                                                                 \
     do {                                                                                           \
@@ -94,17 +106,26 @@ int create3d(rbc_handle *h)
     s->fft_lds = ((size_t)2 * rbc3::slab_row(c.nx) * ny + c.nx + ny) * sizeof(double2);
     { const int items = 8 * (c.nx > ny ? c.nx : ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
     if (h->stream2d) s->fft_threads = c.nx >= 256 ? 256 : (c.nx + 63) / 64 * 64;      // a "slab" is one row: one work item per point
-    if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_THREADS")) s->fft_threads = std::atoi(e);
+    if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_THREADS")) {            // A/B knob of the slab-FFT workgroup size
+        const int v = std::atoi(e);
+        if (v < 64 || v > 1024 || v % 64) return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_FFT_THREADS must be a multiple of 64 in [64, 1024]");
+        s->fft_threads = v;
+    }
     if (h->stream2d && c.nz % 2 == 0 && !h->no_pair) {      // several row pairs per workgroup (k2s_rhs_fft_pair / k2s_ifft_pair)
         int R = 16;
-        if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_ROWS")) R = std::atoi(e);
+        if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_ROWS")) {
+            R = std::atoi(e);
+            if (R < 1 || R > 64 || (R & (R - 1))) return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_FFT_ROWS must be a power of two in [1, 64]");
+        }
         if (const char *e = std::getenv("RBC_EXPERIMENT_FFT2D_THREADS")) s->thr2d = std::atoi(e);
         if (s->thr2d > 256 || s->thr2d < 64) s->thr2d = 256;          // the kernels' launch bound
         while (R > 1 && ((c.nz / 2) % R != 0 || (size_t)(2 * R * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2) > 128 * 1024)) R /= 2;
         s->rows2d = R < 1 ? 1 : R;
         s->fft2d_lds = (size_t)(2 * s->rows2d * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
-        HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_rhs_fft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft2d_lds));
-        HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_ifft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft2d_lds));
+        if (s->fft2d_lds > (size_t)RBC_LDS_CEILING)
+            return fail(RBC_ERR_INVALID, "streaming 2D: a row pair of this nx does not fit the LDS FFT (nx <= ~3400)");
+        RBC_LDS_ATTR(rbc3::k2s_rhs_fft_pair);
+        RBC_LDS_ATTR(rbc3::k2s_ifft_pair);
         // the whole projection as one kernel where an env's packed spectrum fits the LDS and nx = 8 * {4, 6, 8, 12, 16, 24}
         const size_t need = ((size_t)(c.nz / 2) * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
         const char *nf = std::getenv("RBC_NO_FUSE_PROJECT");
@@ -112,7 +133,7 @@ int create3d(rbc_handle *h)
         const bool fast_rows = s->plan.nx2 == 8 && (n1 == 4 || n1 == 6 || n1 == 8 || n1 == 12 || n1 == 16 || n1 == 24 || n1 == 32) && c.nx <= 256;
         if (fast_rows && need <= 150 * 1024 && !(nf && nf[0] == '1')) {
             s->fuse2d = n1; s->fuse2d_lds = need;
-#define RBC_FUSE_ATTR(N1_) HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_project_fused<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+#define RBC_FUSE_ATTR(N1_) RBC_LDS_ATTR(rbc3::k2s_project_fused<N1_>);
             RBC_FUSE_ATTR(4) RBC_FUSE_ATTR(6) RBC_FUSE_ATTR(8) RBC_FUSE_ATTR(12) RBC_FUSE_ATTR(16) RBC_FUSE_ATTR(24) RBC_FUSE_ATTR(32)
 #undef RBC_FUSE_ATTR
         } else if (fast_rows) {          // the spectrum of an env does not fit: separate kernels with the in-place row FFT
@@ -121,8 +142,8 @@ int create3d(rbc_handle *h)
             s->ip2d = n1; s->rows2d = Rr;
             s->ip2d_lds = ((size_t)Rr * rbc3::slab_row(c.nx) + c.nx) * sizeof(double2);
 #define RBC_IP_ATTR(N1_)                                                                                                                 \
-            HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_rhs_fft_pair_ip<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->ip2d_lds)); \
-            HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k2s_ifft_pair_ip<N1_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->ip2d_lds));
+            RBC_LDS_ATTR(rbc3::k2s_rhs_fft_pair_ip<N1_>); \
+            RBC_LDS_ATTR(rbc3::k2s_ifft_pair_ip<N1_>);
             RBC_IP_ATTR(4) RBC_IP_ATTR(6) RBC_IP_ATTR(8) RBC_IP_ATTR(12) RBC_IP_ATTR(16) RBC_IP_ATTR(24) RBC_IP_ATTR(32)
 #undef RBC_IP_ATTR
         }
@@ -182,12 +203,26 @@ int create3d(rbc_handle *h)
             HIP3(hipMemcpy(s->partner, pa.data(), pa.size() * sizeof(int), hipMemcpyHostToDevice));
         }
     }
-    {   // RBC_3D_GROUPS=n overrides the default (4 groups of >= 4 envs for 3D handles; streaming-2D batches are large: 1)
-        int want = h->stream2d ? 1 : 4;
+    {   // RBC_3D_SLICES=n: experiment knob, default 1.  Measured (B = 1024 at 128 x 64, 650 MB in flight): 2 / 4 / 8 slices run at
+        // 22.9k / 21.0k / 16.2k env-steps/s against 24.5k unsliced -- what the Infinity Cache returns (+37 % on a pure copy) is less
+        // than what the four-times-smaller launches lose; configs[4] (B = 32, 304 MB): 4.4k sliced in two against 4.8k.
+        const int min_envs = h->stream2d ? 64 : 8;
+        int sl = 1;
+        if (const char *e = std::getenv("RBC_3D_SLICES")) sl = std::atoi(e);
+        if (sl > 64) sl = 64;
+        while (sl > 1 && h->B / sl < min_envs) --sl;
+        s->slices = sl < 1 ? 1 : sl;
+    }
+    {   // RBC_3D_GROUPS=n overrides the default: 4 groups of >= 4 envs for 3D handles; streaming-2D: 3 chains once every chain still
+        // fills the chip (B >= 768) -- the bandwidth-bound tile kernel of one chain then runs under the latency-bound one-kernel
+        // projection of another (128 x 64, B = 1024: 24.2k / 25.3k / 26.3k / 26.1k env-steps/s with 1 / 2 / 3 / 4 chains)
+        int want = h->stream2d ? (h->B >= 768 ? 3 : 1) : 4;
         if (const char *e = std::getenv("RBC_3D_GROUPS")) want = std::atoi(e);
         if (want > 16) want = 16;
-        while (want > 1 && h->B / want < 4) --want;
+        const int per_slice = (h->B + s->slices - 1) / s->slices;
+        while (want > 1 && per_slice / want < 4) --want;
         s->groups = want < 1 ? 1 : want;
+        if (s->slices > 1 && !std::getenv("RBC_USE_GRAPH")) h->no_graph = false;     // many short launches: replay them as one captured graph
         if (s->groups > 1 && !std::getenv("RBC_USE_GRAPH")) h->no_graph = false;     // several chains: replay them as one captured graph
         if (s->groups > 1) {
             s->gstream.resize(s->groups); s->gdone.resize(s->groups);
@@ -198,10 +233,10 @@ int create3d(rbc_handle *h)
             HIP3(hipEventCreateWithFlags(&s->gstart, hipEventDisableTiming));
         }
     }
-    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
-    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_ifft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
-    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_rhs_fft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
-    HIP3(hipFuncSetAttribute(reinterpret_cast<const void *>(rbc3::k3_ifft_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->fft_lds));
+    RBC_LDS_ATTR(rbc3::k3_rhs_fft);
+    RBC_LDS_ATTR(rbc3::k3_ifft);
+    RBC_LDS_ATTR(rbc3::k3_rhs_fft_pair);
+    RBC_LDS_ATTR(rbc3::k3_ifft_pair);
     return RBC_OK;
 }
 
@@ -234,7 +269,8 @@ inline rbc3_grp whole_batch(const rbc_handle *h) { return rbc3_grp{0, h->B, h->s
 
 // exact projection of state buffer `which` (0/1) of the group's envs with stage step dts (mask: device pointer [B] or null)
 // (want_phi = false: the caller does not need the potential itself afterwards -- only the one-kernel streaming-2D projection can skip its store)
-int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask, bool want_phi = true)
+// (defer_w = true: leave  w -= dts dphi/dz  to the next stage's tile kernels -- see tile_correct_w; mirror-packed path only)
+int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask, bool want_phi = true, bool defer_w = false)
 {
     rbc3_state *s = h->s3;
     const rbc3::Geo3 &g = s->g;
@@ -274,7 +310,7 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
         else
         if (s->rows2d) hipLaunchKernelGGL(rbc3::k2s_ifft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
         else hipLaunchKernelGGL(rbc3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
-        hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
+        if (!defer_w) hipLaunchKernelGGL(rbc3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
 #undef RBC_IP_RHS
 #undef RBC_IP_INV
         HIP3(hipGetLastError());
@@ -367,6 +403,16 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
         auto enough = [&](int kt) { return g.nz % kt == 0 && 2 * (size_t)B * (g.nz / kt) >= 256; };
         shape = enough(16) ? 5 : (enough(8) ? 6 : 7);
     }
+    // RBC_DEFER_W=1: the vertical half of a stage's projection is deferred into the next stage's tile kernels (3D tiles on the
+    // mirror-packed projection) instead of the separate k3_correct_w pass.  Parity-green (tests/test_gpu_parity3d.py), one launch and
+    // 1.2 MB per env and stage less -- and 18 % SLOWER (4.82k against 5.90k env-steps/s at configs[4]): the two phi planes the
+    // correction holds across a level push the 168-register tile kernel from 6 to 20 spilled VGPRs.  Off by default; kept for a
+    // tile kernel with register headroom.
+    const bool can_defer = shape >= 1 && shape <= 4 && !h->stream2d && g.nz % 2 == 0 && !h->no_pair &&
+                           ([] { const char *e = std::getenv("RBC_DEFER_W"); return e && e[0] == '1'; }());
+    const double *phi_g = s->phi + (size_t)q.e0 * g.nc;
+    bool pending = false;                                      // cur holds w* of the previous stage, its phi / dts below
+    double dts_pending = 0.0;
     for (int n = 0; n < nsub; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;
         for (int ph = 0; ph < 3; ++ph) {
@@ -381,7 +427,8 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * rbc3::NXP3 * sizeof(double);                                                        \
-                hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
+                if (pending) hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES, rbc3::NXP3, false, 0, 0, true>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, phi_g, dts_pending); \
+                else hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, (const double *)nullptr, 0.0); \
             }
             // (48, 48) horizontal planes -- configs[4] --, the registry default (32, 32) and the flowstats experiment's (64, 64) have
             // instantiations with nx, ny as compile-time constants: the index arithmetic of the plane staging becomes multiplications
@@ -390,7 +437,8 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * rbc3::NXP3 * sizeof(double);                                                        \
-                hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES, rbc3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
+                if (pending) hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES, rbc3::NXP3, false, NXC_, NYC_, true>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, phi_g, dts_pending); \
+                else hipLaunchKernelGGL((rbc3::k3_tile_all<TY, KT, 2, THR, WAVES, rbc3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, (const double *)nullptr, 0.0); \
             }
             const bool c48 = (g.nx == 48 && g.ny == 48 && !no_nxc), c32 = (g.nx == 32 && g.ny == 32 && !no_nxc), c64 = (g.nx == 64 && g.ny == 64 && !no_nxc);
             if (shape == 1 && c48) RBC_TILE_LAUNCHC(16, 16, 768, 3, 48, 48)
@@ -409,7 +457,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
 #define RBC_FLAT_LAUNCH(KT)                                                                                                              \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.nz / KT))), bt(g.nx);                                                         \
-                hipLaunchKernelGGL((rbc3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(double), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g); \
+                hipLaunchKernelGGL((rbc3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(double), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, (const double *)nullptr, 0.0); \
             }
             else if (shape == 5) RBC_FLAT_LAUNCH(16)
             else if (shape == 6) RBC_FLAT_LAUNCH(8)
@@ -429,8 +477,12 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
                 hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
                 hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, q.st, g, cur, nxt, gm, phy, actT, ra, d, gam[ph], zet[ph], B, (double *)nullptr);
             }
-            // the potential is an output (pNHS) only after the last stage of the control interval
-            if (int rc = project3d(h, q, which ^ 1, (gam[ph] + zet[ph]) * d, nullptr, n == nsub - 1 && ph == 2)) return rc;
+            // the potential is an output (pNHS) only after the last stage of the control interval; that stage also completes
+            // its own projection (outputs and the next env-step read the projected state)
+            const bool last = (n == nsub - 1 && ph == 2);
+            const double dts = (gam[ph] + zet[ph]) * d;
+            if (int rc = project3d(h, q, which ^ 1, dts, nullptr, last, can_defer && !last)) return rc;
+            pending = can_defer && !last; dts_pending = dts;
             which ^= 1;
         }
     }
@@ -446,24 +498,28 @@ int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, dou
 {
     rbc3_state *s = h->s3;
     int which = s->cur;
-    if (s->groups <= 1) {
-        const rbc3_grp q = whole_batch(h);
-        if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
-        if (int rc = output3d(h, q, which, nullptr)) return rc;
-        s->cur = which;
-        return RBC_OK;
-    }
-    HIP3(hipEventRecord(s->gstart, h->stream));
-    const int per = (h->B + s->groups - 1) / s->groups;
-    for (int gi = 0; gi < s->groups; ++gi) {
-        const int e0 = gi * per, Bg = (e0 + per <= h->B) ? per : h->B - e0;
-        if (Bg <= 0) continue;
-        const rbc3_grp q{e0, Bg, s->gstream[gi]};
-        HIP3(hipStreamWaitEvent(q.st, s->gstart, 0));
-        if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
-        if (int rc = output3d(h, q, which, nullptr)) return rc;
-        HIP3(hipEventRecord(s->gdone[gi], q.st));
-        HIP3(hipStreamWaitEvent(h->stream, s->gdone[gi], 0));
+    const int per_slice = (h->B + s->slices - 1) / s->slices;
+    for (int sl = 0; sl < s->slices; ++sl) {                      // slices run one after the other (stream order / join events)
+        const int s0 = sl * per_slice, Bs = (s0 + per_slice <= h->B) ? per_slice : h->B - s0;
+        if (Bs <= 0) continue;
+        if (s->groups <= 1) {
+            const rbc3_grp q{s0, Bs, h->stream};
+            if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
+            if (int rc = output3d(h, q, which, nullptr)) return rc;
+            continue;
+        }
+        HIP3(hipEventRecord(s->gstart, h->stream));
+        const int per = (Bs + s->groups - 1) / s->groups;
+        for (int gi = 0; gi < s->groups; ++gi) {
+            const int e0 = s0 + gi * per, Bg = (gi * per + per <= Bs) ? per : Bs - gi * per;
+            if (Bg <= 0) continue;
+            const rbc3_grp q{e0, Bg, s->gstream[gi]};
+            HIP3(hipStreamWaitEvent(q.st, s->gstart, 0));
+            if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
+            if (int rc = output3d(h, q, which, nullptr)) return rc;
+            HIP3(hipEventRecord(s->gdone[gi], q.st));
+            HIP3(hipStreamWaitEvent(h->stream, s->gdone[gi], 0));
+        }
     }
     s->cur = which;
     return RBC_OK;
@@ -488,7 +544,7 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
             int rc = run_step3d(h, h->d_actions, nsub, dt, dt_last);
             hipError_t e = hipStreamEndCapture(h->stream, &graph);
             s->cur = par;                               // capture executed nothing: undo the host-side flips
-            if (rc) return rc;
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return fail(RBC_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
             HIP3(hipGraphInstantiate(&s->gexec[par], graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);

@@ -509,12 +509,27 @@ __device__ __forceinline__ void tile_store(const TG &t, double *dst, const doubl
     }
 }
 
+// Deferred vertical half of the previous stage's projection (DEFW = true): the inverse-FFT kernel has corrected u and v
+// (it holds phi of its slab in LDS), but  w -= dts dphi/dz  needs phi of the slab below and used to be a pass of its own
+// (k3_correct_w: read w, read phi twice, write w, one more launch per stage).  Instead the state buffer keeps w* and the
+// tendency kernels of the NEXT stage apply the correction to every w value as they load it -- planes while they are staged,
+// own-column window values as they are fetched: w(kf) -= (phi(kf) - phi(kf-1)) * rdz * dts on the interior faces 1..nz-1 (the
+// same expression and operation order as k3_correct_w).  Only the last stage of an env-step still runs k3_correct_w, so that
+// outputs and the next env-step see the projected state.
+template <int NPF>
+__device__ __forceinline__ void tile_correct_w(double (&wv)[NPF], const double (&pn)[NPF], const double (&pp)[NPF], double rdz, double dts)
+{
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) wv[q] -= (pn[q] - pp[q]) * rdz * dts;
+}
+
 // (u, v): blockDim = nx * TY3, B * (ny/TY3) * (nz/KT3) workgroups, LDS = 3 planes.  Two shapes are built:
 // 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
 // (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
-template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0, bool DEFW = false>
 __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, double *nxt, double *gm,
-                                             const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
+                                             const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk,
+                                             const double *phi = nullptr, double dts_prev = 0.0)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
     const TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC> t(g, blk);
@@ -548,12 +563,24 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
     if constexpr (!FLAT) tile_fetch(t, v + (size_t)t.k0 * pl, pfv);
     tile_fetch(t, w + (size_t)t.k0 * pl, pfw);
     tile_fetch(t, w + (size_t)min(t.k0 + 1, nz) * pl, pfw1);
+    // DEFW: phi planes k0-1, k0, k0+1 for the two w planes of the prologue; pfp then holds phi of the last staged face level
+    const double *ph = DEFW ? phi + (size_t)t.env * g.nc : nullptr;
+    double pfp[NPF], pfq[NPF], pfn[NPF];
+    if constexpr (DEFW) {
+        tile_fetch(t, ph + (size_t)max(t.k0 - 1, 0) * pl, pfq);
+        tile_fetch(t, ph + (size_t)t.k0 * pl, pfn);
+        tile_fetch(t, ph + (size_t)min(t.k0 + 1, nz - 1) * pl, pfp);
+    }
     double winu[6], winv[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) { winu[q] = own(u, t.k0 - 3 + q); winv[q] = FLAT ? 0.0 : own(v, t.k0 - 3 + q); }
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     double nu5 = own(u, t.k0 + 3), nv5 = FLAT ? 0.0 : own(v, t.k0 + 3);
     double ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : 0.0, ngv = (use_gm && !FLAT) ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : 0.0;
+    if constexpr (DEFW) {
+        if (t.k0 > 0) tile_correct_w(pfw, pfn, pfq, rdz, dts_prev);           // face k0 (the wall face 0 carries no correction)
+        if (t.k0 + 1 < nz) tile_correct_w(pfw1, pfp, pfn, rdz, dts_prev);     // face k0 + 1
+    }
     tile_store(t, PW, pfw);                                       // w(k0) first: bottom-face terms of the chunk
     __syncthreads();
     double fbu = 0.0, dwbu = 0.0, fdnu, fbv = 0.0, dwbv = 0.0, fdnv;
@@ -584,6 +611,7 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
             tile_fetch(t, u + (size_t)(k + 1) * pl, pfu);
             if constexpr (!FLAT) tile_fetch(t, v + (size_t)(k + 1) * pl, pfv);
             tile_fetch(t, w + (size_t)min(k + 2, nz) * pl, pfw);
+            if constexpr (DEFW) tile_fetch(t, ph + (size_t)min(k + 2, nz - 1) * pl, pfn);
             nu5 = own(u, k + 4);
             if constexpr (!FLAT) nv5 = own(v, k + 4);
             if (use_gm) { ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; if constexpr (!FLAT) ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; }
@@ -650,6 +678,11 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
             fbv = ft; dwbv = dwt; fdnv = f0;
         }
         if (more) {
+            if constexpr (DEFW) {
+                if (k + 2 < nz) tile_correct_w(pfw, pfn, pfp, rdz, dts_prev);
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) pfp[q] = pfn[q];
+            }
             __syncthreads();                                      // every read of this level's planes is done
             tile_store(t, PU, pfu);
             if constexpr (!FLAT) tile_store(t, PV, pfv);
@@ -660,9 +693,10 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const double *cur, d
 }
 
 // (w, b): same shape, LDS = 2 planes (w and b at the current level)
-template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0, bool DEFW = false>
 __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, double *nxt, double *gm, const double *actT,
-                                             const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk)
+                                             const double *nu_kappa, double dt, double gam, double zet, int store_g, int blk,
+                                             const double *phi = nullptr, double dts_prev = 0.0)
 {
     extern __shared__ __attribute__((aligned(16))) double tile_sm[];
     const TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC> t(g, blk);
@@ -686,13 +720,27 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
     auto ghost_lo = [&](double c1, double bc) -> double { return c1 + ((c1 - bc) / hz) * (-dz); };
     auto ghost_hi = [&](double cN, double bc) -> double { return cN + ((bc - cN) / hz) * dz; };
     auto cen = [&](const double *f, int c, int kk) -> double { return f[(size_t)min(max(kk, 0), nz - 1) * pl + c]; };
-    auto fac = [&](int kk) -> double { return w[(size_t)min(max(kk, 0), nz) * pl + col]; };
+    const double *ph = DEFW ? phi + (size_t)t.env * g.nc : nullptr;
+    auto fac = [&](int kk) -> double {                            // own-column w face; DEFW: with the deferred correction applied
+        const int kc = min(max(kk, 0), nz);
+        const double wv = w[(size_t)kc * pl + col];
+        if constexpr (DEFW) {
+            const int kp = min(max(kc, 1), nz - 1);               // clamped so that the loads stay inside phi; unused at the walls
+            const double pn = ph[(size_t)kp * pl + col], pp = ph[(size_t)(kp - 1) * pl + col];
+            return (kc >= 1 && kc <= nz - 1) ? wv - (pn - pp) * rdz * dts_prev : wv;
+        } else return wv;
+    };
 
     // every global load of the prologue before the first barrier (see k3_tile_uv)
     const size_t eb = (size_t)t.env * g.env_stride;
     const bool use_gm = (zet != 0.0);                             // stage 1 never reads G^- (see k3_tendency)
     double pfw[NPF], pfb[NPF];
     tile_fetch(t, w + (size_t)t.k0 * pl, pfw); tile_fetch(t, b + (size_t)t.k0 * pl, pfb);
+    double pfp[NPF], pfn[NPF];                                    // DEFW: phi planes of the last / the next staged w level
+    if constexpr (DEFW) {
+        tile_fetch(t, ph + (size_t)max(t.k0 - 1, 0) * pl, pfn);
+        tile_fetch(t, ph + (size_t)t.k0 * pl, pfp);
+    }
     double winw[6], winb[6], au[6], eu[6], av[6], ev[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -707,6 +755,7 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
     double fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : 0.0;
     double fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : 0.0;
     double bdn = (t.k0 > 0) ? winb[2] : ghost_lo(winb[3], bottom_T(g, actT + (size_t)t.env * wall_stride(g), t.i, t.j));
+    if constexpr (DEFW) { if (t.k0 > 0) tile_correct_w(pfw, pfp, pfn, rdz, dts_prev); }
     tile_store(t, PW, pfw); tile_store(t, PB, pfb);
     __syncthreads();
 
@@ -722,6 +771,7 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
         const double gpw_ = ngw, gpb_ = ngb;
         if (more) {
             tile_fetch(t, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, b + (size_t)(k + 1) * pl, pfb);
+            if constexpr (DEFW) tile_fetch(t, ph + (size_t)(k + 1) * pl, pfn);       // k + 1 <= nz - 1 here
             nw5 = fac(k + 4); nb5 = cen(b, col, k + 4);
             nau = cen(u, col, k + 3); neu = cen(u, colE, k + 3);
             if constexpr (!FLAT) { nav = cen(v, col, k + 3); nev = cen(v, colN, k + 3); }
@@ -781,6 +831,11 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
             fbb = ft; bdn = b0;
         }
         if (more) {
+            if constexpr (DEFW) {
+                tile_correct_w(pfw, pfn, pfp, rdz, dts_prev);
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) pfp[q] = pfn[q];
+            }
             __syncthreads();
             tile_store(t, PW, pfw); tile_store(t, PB, pfb);
             __syncthreads();
@@ -793,13 +848,14 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const double *cur, d
 // read the same state buffer and write disjoint fields).  A kernel boundary on the dependent stream costs about 10 us on this
 // path whatever the kernels do (2.5 ms per env-step at B = 1, where all 234 launches are nearly empty); one launch fewer per
 // stage is worth more here than anything done inside the kernels.
-template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0, bool DEFW = false>
 __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_all(Geo3 g, const double *cur, double *nxt, double *gm, const double *actT,
-                                                   const double *nu_kappa, double dt, double gam, double zet, int store_g)
+                                                   const double *nu_kappa, double dt, double gam, double zet, int store_g,
+                                                   const double *phi, double dts_prev)
 {
     const int half = gridDim.x >> 1;                 // first half of the grid: (u, v); second half: (w, b), starting as the first drains
-    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half);
-    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x);
+    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC, DEFW>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half, phi, dts_prev);
+    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC, DEFW>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x, phi, dts_prev);
 }
 
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------

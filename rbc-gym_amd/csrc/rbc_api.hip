@@ -647,7 +647,7 @@ int rbc_debug_cell_distances(int device, const float *uy, int B, int nx, double 
 void *rbc_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable)   /* portable: page-locked for every device of the node (multi-GPU vector env) */ != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 

@@ -33,6 +33,7 @@ class ShardedSim:
             self.close()
             raise
         self.B = int(num_envs)
+        self._broken = None
         self._pool = ThreadPoolExecutor(max_workers=len(devices), thread_name_prefix="rbc-shard")
         first = self.sims[0]
         self.lib, self.heaters = first.lib, first.heaters
@@ -45,10 +46,28 @@ class ShardedSim:
         s, c = self.ranges[r]
         return a[s:s + c]
 
-    def _all(self, fn):
-        """fn(r, sim) on every shard concurrently; results in shard order; the first exception is re-raised"""
+    def _all(self, fn, mutating=False):
+        """fn(r, sim) on every shard concurrently; results in shard order; the first exception is re-raised.
+        A MUTATING call (reset / step / set_*) that fails on one shard has still run on the others: their clocks,
+        states and autoreset masks are then out of step with the failed one, so the sharded env marks itself broken and
+        refuses every further call but close() -- build a new env (the reference's per-process envs die the same way:
+        a RuntimeError out of one worker's step ends the AsyncVectorEnv)."""
+        if self._broken is not None:
+            raise RuntimeError(f"sharded env is broken after a failed call on one shard ({self._broken}); close it and make a new one")
         futs = [self._pool.submit(fn, r, sim) for r, sim in enumerate(self.sims)]
-        return [f.result() for f in futs]
+        out, first = [], None
+        for r, f in enumerate(futs):
+            try:
+                out.append(f.result())
+            except Exception as e:                      # collect every shard before raising: no call is left in flight
+                out.append(None)
+                if first is None:
+                    first = (r, e)
+        if first is not None:
+            if mutating:
+                self._broken = f"shard {first[0]} on device {self.devices[first[0]]}: {first[1]}"
+            raise first[1]
+        return out
 
     def _split(self, a, dtype=None):
         if a is None:
@@ -62,31 +81,31 @@ class ShardedSim:
     def reset(self, seeds, mask=None):
         s = self._split(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.B,)))
         m = self._split(mask)
-        self._all(lambda r, sim: None if (m[r] is not None and not np.any(m[r])) else sim.reset(s[r], mask=m[r]))
+        self._all(lambda r, sim: None if (m[r] is not None and not np.any(m[r])) else sim.reset(s[r], mask=m[r]), mutating=True)
 
     def reset_from_arrays(self, *fields, mask=None):
         f = [self._split(x) for x in fields]
         m = self._split(mask)
-        self._all(lambda r, sim: None if (m[r] is not None and not np.any(m[r])) else sim.reset_from_arrays(*[x[r] for x in f], mask=m[r]))
+        self._all(lambda r, sim: None if (m[r] is not None and not np.any(m[r])) else sim.reset_from_arrays(*[x[r] for x in f], mask=m[r]), mutating=True)
 
     def set_rayleigh(self, ra):
         v = self._split(np.broadcast_to(np.asarray(ra, np.float64), (self.B,)))
-        self._all(lambda r, sim: sim.set_rayleigh(v[r]))
+        self._all(lambda r, sim: sim.set_rayleigh(v[r]), mutating=True)
 
     def set_obs_normalization(self, *a, **kw):
-        self._all(lambda r, sim: sim.set_obs_normalization(*a, **kw))
+        self._all(lambda r, sim: sim.set_obs_normalization(*a, **kw), mutating=True)
 
     # -- step_simulation ---------------------------------------------------------------------------------
     def step(self, actions):
         a = self._split(actions, np.float32)
-        return all(self._all(lambda r, sim: sim.step(a[r])))
+        return all(self._all(lambda r, sim: sim.step(a[r]), mutating=True))
 
     def step_dev(self, actions_dev_ptrs):
         """one device pointer per shard (each on that shard's GPU), float32 [count][heaters...]"""
         ptrs = list(actions_dev_ptrs)
         if len(ptrs) != len(self.sims):
             raise ValueError("step_dev on a sharded env takes one device pointer per shard")
-        self._all(lambda r, sim: sim.step_dev(ptrs[r]))
+        self._all(lambda r, sim: sim.step_dev(ptrs[r]), mutating=True)
 
     # -- getters ---------------------------------------------------------------------------------------------
     def _cat(self, parts):

@@ -37,6 +37,20 @@ def reduce_run(elapsed, nan_envs, device=None, dist=None):
     return float(t.item()), int(n.item())
 
 
+def gather_run(elapsed, nan_envs, device=None, dist=None):
+    """-> (per-rank elapsed seconds, per-rank NaN-env counts), rank-major lists: a straggler GPU shows up here while
+    `reduce_run` only keeps the maximum.  Identity (one-element lists) when not distributed."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(elapsed)], [int(nan_envs)]
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([float(elapsed), float(nan_envs)], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = torch.stack(parts).cpu()
+    return [float(x) for x in out[:, 0]], [int(round(float(x))) for x in out[:, 1]]
+
+
 def gather_observations(local_obs, dist=None):
     """Optional exchange step when the policy lives on one GPU: all-gather of the per-rank
     observation batches, rank-major, i.e. in global env order for contiguous equal shards.  `local_obs` is a torch

@@ -32,7 +32,9 @@ def test_bench_line_2d_small_batch():
     assert abs(r["algorithmic_bytes_per_launch"] - 64 * 50 * 10 * 3 * 6144 * 8) < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == "env-steps/s"
-    assert d["nan_envs"] == 0
+    # the stated core count must describe compute actually obtained: N workers deliver at least half of N single workers
+    assert c["cores"] <= c["affinity"] and c["single_worker"] > 0 and c["cores_effective"] > 0.5 * c["cores"], c
+    assert d["nan_envs"] == 0 and d["per_rank"]["nan_envs"] == [0]
 
 
 @pytest.mark.gpu
@@ -75,7 +77,13 @@ def test_self_launched_two_rank_rehearsal_on_one_gpu():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["cpu_baseline"] is None and d["nan_envs"] == 0
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["nan_envs"] == 0
+    # the CPU baseline is measured by the self-launching parent, before the ranks exist, and handed to rank 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["single_worker"] > 0
+    # a straggler GPU must be visible: per-rank timings and NaN counts next to the max / sum
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and pr["nan_envs"] == [0, 0] and abs(max(pr["ms_per_step"]) - d["ms_per_step"]) < 1e-9
     assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
@@ -89,5 +97,10 @@ def test_extra_keys_are_measured_in_the_same_run():
     c4 = x["config4_3d"]
     assert c4["nan_envs"] == 0 and c4["value"] > 0 and "32x48x48" in c4["config"]["workload"]
     assert d["roofline"]["on_box_copy_gbs"] == x["copy_ceiling"]["kernel_gbs"]
+    rs = x["ra_sweep_config3"]                              # BASELINE.json configs[3] per GPU: thirds at Ra 1e4 / 1e5 / 1e6
+    assert set(rs["nan_envs_per_ra"]) == {"10000", "100000", "1e+06"} and sum(rs["nan_envs_per_ra"].values()) == 0 and rs["value"] > 0
+    assert 2.0 < rs["mean_nusselt_state_per_ra"]["10000"] < 6.5 and rs["mean_nusselt_state_per_ra"]["1e+06"] > rs["mean_nusselt_state_per_ra"]["10000"]
+    sc = x["steady_ckpt"]                                   # the reference's stored steady states stay put under zero action
+    assert sc["nan_envs"] == 0 and abs(sc["kinetic_energy"] / sc["reference_kinetic_energy"] - 1) < 1e-4 and sc["max_rel_ke_drift_per_env_step"] < 1e-4
     s2 = x["streaming_2d_128x64"]                           # a grid without an LDS-resident kernel: the streaming 2D path
     assert s2["nan_envs"] == 0 and s2["value"] > 0 and 0.0 < s2["mean_nusselt_state"] < 6.0

@@ -37,7 +37,8 @@ def oracle():
     dict(nx=32, nz=24, heaters=4, heater_limit=0.75, obs=(6, 16), dt_solver=0.03, dt_control=0.07, ra=3e3, lx=3.0),  # DFT-4 x 8
     dict(nx=192, nz=128, heaters=12, heater_limit=0.75, obs=(8, 48), dt_solver=0.01, dt_control=0.025, ra=1e5),     # spectrum too large for one workgroup: in-place separate kernels (DFT-24 x 8)
     dict(nx=256, nz=128, heaters=12, heater_limit=0.75, obs=(8, 64), dt_solver=0.01, dt_control=0.025, ra=1e6),     # DFT-32 x 8
-], ids=["128x64", "192x32", "256x64", "100x40", "72x27", "64x40", "48x24", "32x24", "192x128", "256x128"])
+    dict(nx=384, nz=32, heaters=12, heater_limit=0.75, obs=(8, 48), dt_solver=0.01, dt_control=0.025, ra=1e5, lx=8 * np.pi),  # nx > 256: no FLAT tiles, no in-place FFT -- generic DFT, z-marching tendencies
+], ids=["128x64", "192x32", "256x64", "100x40", "72x27", "64x40", "48x24", "32x24", "192x128", "256x128", "384x32"])
 def test_streaming_2d_grids_match_oracle(native, oracle, cfg):
     """random reset, then two actuated control intervals (incl. a clipped last substep where dt_control is not a multiple
     of dt_solver): fields at round-off of the oracle, Nusselt numbers, float32 observations (all five channels)."""
@@ -224,3 +225,45 @@ def test_gym_env_on_a_streaming_grid(native):
     d = venv.sim.get_cell_distances(0.001)
     assert d.shape == (3,) and np.isfinite(d).all()
     venv.close()
+
+
+def test_reward_shaping_falls_back_to_the_numpy_search_on_a_wide_grid(native):
+    """`rbc_get_cell_distances` is one wave per mid-line (nx <= 256); on a wider streaming grid the vector wrapper must take
+    the numpy peak search (wrappers.cell_distances on info['state']) instead of raising on every step."""
+    import rbc_gym  # noqa: F401
+    from rbc_gym._gym import gym
+    from rbc_gym.wrappers import VectorRBCRewardShaping, cell_distances
+    venv = gym.make_vec("rbc_gym/RayleighBenardConvection2D-v0", num_envs=2, state_shape=[32, 384], observation_shape=[8, 48], heater_duration=0.06)
+    with pytest.raises(native.RbcError):
+        venv.reset(seed=1)
+        venv.sim.get_cell_distances(0.001)
+    shaped = VectorRBCRewardShaping(venv, shaping_weight=0.5)
+    shaped.reset(seed=1)
+    for _ in range(2):
+        obs, rew, term, trunc, info = shaped.step(np.zeros((2, 12), np.float32))
+    assert shaped.device_search is False and np.isfinite(rew).all()
+    state = venv.sim.get_state(3)
+    assert np.array_equal(info["cell_dist"], cell_distances(state[:, 2, 32 // 2 - 1]))
+    venv.close()
+
+
+def test_two_live_handles_of_different_grids_step_alternately(native):
+    """The dynamic-LDS ceiling of a kernel is process state: creating a handle on a smaller grid must not lower it under a
+    live handle on a larger one (128x128 needs > 64 KiB in the row-FFT kernels, 128x32 far less; 3D: 64x64 vs 32x32 slabs)."""
+    big = native.NativeSim(batch=2, nx=192, nz=128, obs_nx=48, obs_nz=8, dt_control=0.03, dt_solver=0.01)
+    big.reset(np.array([1, 2], dtype=np.uint64))
+    small = native.NativeSim(batch=2, nx=128, nz=64, obs_nx=64, obs_nz=8, dt_control=0.03, dt_solver=0.01)      # created AFTER: would have lowered the ceiling
+    small.reset(np.array([3, 4], dtype=np.uint64))
+    b3 = native.NativeSim3D(batch=4, shape=(16, 64, 64), dt_control=0.02, dt_solver=0.01)
+    b3.reset(np.arange(4, dtype=np.uint64))
+    s3 = native.NativeSim3D(batch=4, shape=(16, 32, 32), dt_control=0.02, dt_solver=0.01)
+    s3.reset(np.arange(4, dtype=np.uint64))
+    for _ in range(2):
+        assert big.step(np.zeros((2, 12), np.float32)) and small.step(np.zeros((2, 12), np.float32))
+        assert b3.step(np.zeros((4, 8, 8), np.float32)) and s3.step(np.zeros((4, 8, 8), np.float32))
+    for sim in (big, small):
+        assert np.isfinite(sim.get_nusselt()[0]).all()
+    for sim in (b3, s3):
+        assert np.isfinite(sim.get_nusselt()).all()
+    for sim in (big, small, b3, s3):
+        sim.close()

@@ -46,6 +46,8 @@ def _worker(rank, world, port, q):
     res = _step_envs(range(start, start + count))
     sharding.barrier(dist)
     elapsed, nans = sharding.reduce_run(1.0 + rank, rank, dist=dist)     # rank-dependent inputs: MAX / SUM visible
+    per_rank = sharding.gather_run(1.0 + rank, rank, dist=dist)          # ... and the per-rank lists of the N>1 bench line
+    assert per_rank == ([1.0, 2.0], [0, 1]), per_rank
     import torch
     local = torch.arange(start, start + count, dtype=torch.float32).reshape(count, 1, 1).expand(count, 3, 2).contiguous()
     obs = sharding.gather_observations(local, dist)                       # optional policy-side exchange
@@ -146,3 +148,42 @@ def test_sharded_sim_concatenates_in_global_env_order():
     with pytest.raises(ValueError):
         ShardedSim(make, 2, [0, 1, 2])
     sh.close()
+
+
+def test_sharded_sim_marks_itself_broken_after_a_failed_mutating_call():
+    """A step that fails on one shard has still advanced the others (clocks and autoreset masks out of step across the
+    batch): the sharded env then refuses every further call but close().  Host logic only: fake handles, no GPU."""
+    import numpy as np
+    from rbc_gym.sharded import ShardedSim
+
+    class Fake:
+        lib, heaters = None, 12
+
+        def __init__(self, count, dev):
+            self.count, self.dev, self.steps, self.closed = count, dev, 0, False
+
+        def step(self, a):
+            if self.dev == 1 and self.steps == 1:
+                raise RuntimeError("device lost")
+            self.steps += 1
+            return True
+
+        def get_flags(self):
+            return np.zeros(self.count, np.int32)
+
+        def close(self):
+            self.closed = True
+
+    s = ShardedSim(Fake, 5, devices=[0, 1])
+    acts = np.zeros((5, 12), np.float32)
+    assert s.step(acts) is True
+    with pytest.raises(RuntimeError, match="device lost"):
+        s.step(acts)
+    assert [f.steps for f in s.sims] == [2, 1]                         # the healthy shard went ahead: the batch is inconsistent
+    with pytest.raises(RuntimeError, match="broken"):
+        s.get_flags()
+    with pytest.raises(RuntimeError, match="broken"):
+        s.step(acts)
+    sims = list(s.sims)
+    s.close()
+    assert all(f.closed for f in sims)
