@@ -206,7 +206,8 @@ def latest_profile(pattern, match):
             d = json.load(open(path))
         except Exception:
             continue
-        if all(d.get("workload_key", {}).get(k) == v for k, v in match.items()):
+        key = d.get("workload_key", {})
+        if all(key.get(k, "f64" if k == "precision" else None) == v for k, v in match.items()):     # (profiles older than the float32 3D path carry no precision: float64)
             return d, os.path.relpath(path, ROOT)
     return None, None
 
@@ -224,11 +225,11 @@ def timed_loop(torch, dev, barrier, fn, K):
     return time.perf_counter() - t0
 
 
-def run_3d(ctx, B, K, W, ra):
+def run_3d(ctx, B, K, W, ra, precision="f64"):
     """configs[4]: 3D 32x48x48, Ra=1e4, heater_duration 0.125, dt_solver 0.01 (13 RK3 substeps per env-step)."""
     torch, np, _native, sharding = ctx["torch"], ctx["np"], ctx["_native"], ctx["sharding"]
     dev, rank, world = ctx["dev"], ctx["rank"], ctx["world"]
-    sim = _native.NativeSim3D(batch=B, device=ctx["local_rank"], shape=(32, 48, 48), ra=ra)
+    sim = _native.NativeSim3D(batch=B, device=ctx["local_rank"], shape=(32, 48, 48), ra=ra, precision=precision)
     start, count = sharding.shard(world * B, world, rank)
     sim.reset(sharding.env_seeds(1234, start, count))
     gen = torch.Generator(device=dev)
@@ -248,13 +249,13 @@ def run_3d(ctx, B, K, W, ra):
     alg = sim.algorithmic_bytes_per_env_step() * B
     avg = float(np.mean(ms)) if len(ms) else float("nan")
     ach = alg / (avg * 1e-3) / 1e9
-    prof, src = latest_profile("*_3d_summary.json", {"dim": 3, "batch": B, "ra": ra})
+    prof, src = latest_profile("*_3d_summary.json", {"dim": 3, "batch": B, "ra": ra, "precision": precision})
     traffic = prof.get("hbm_traffic_bytes_per_env_step_batch") if prof else None
     sim.close()
     return {
         "metric": "env-steps/sec (batched 3D RBC 32x48x48 Ra=1e4)", "value": world * B * K / elapsed, "unit": "env-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
         "config": {"workload": f"configs[4]: batched 3D envs, batch={B} per GPU, grid 32x48x48, Ra={ra:g}, heater_duration 0.125 "
                                "(x t_ff=4) = 13 RK3 substeps per env-step, dt_solver 0.01", "global_batch": world * B,
                    "parallelism": f"env-sharded x{world} (no collective on the step path)"},
@@ -263,7 +264,7 @@ def run_3d(ctx, B, K, W, ra):
                      "measured_hbm_gbs": (traffic / (avg * 1e-3) / 1e9) if traffic else None,
                      "kernel": "rbc3 stage sequence x 39 per env-step (one 'launch' = one env-step of the batch)",
                      "kernel_ms_avg": avg, "algorithmic_bytes_per_launch": alg,
-                     "note": "algorithmic bytes = 10*F*C*s per substep (F=4, C=73728, s=8) x 13 x batch"},
+                     "note": f"algorithmic bytes = 10*F*C*s per substep (F=4, C=73728, s={8 if precision == 'f64' else 4}) x 13 x batch"},
         "nan_envs": nan_total, "mean_nusselt": float(np.mean(nu)),
         "per_rank": {"ms_per_step": [e / K * 1e3 for e in rank_elapsed], "nan_envs": rank_nan}}
 
@@ -536,6 +537,10 @@ def main():
                 d3 = run_3d(ctx, 32, 5, 2, 1e4)
                 extra["config4_3d"] = {k: d3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                           "nan_envs", "mean_nusselt")}
+                if _native.has_precision("f32"):           # the float32 instantiation of the same 3D kernels (153 MB algorithmic per env-step)
+                    d3f = run_3d(ctx, 32, 5, 2, 1e4, "f32")
+                    extra["config4_3d_fp32"] = {k: d3f[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
+                                                                    "roofline", "nan_envs", "mean_nusselt")}
                 if not f32 and _native.has_precision("f32"):
                     s32 = _native.NativeSim(batch=B, device=local_rank, ra=args.ra, precision=1)
                     s32.reset(sharding.env_seeds(1234, 0, B))

@@ -67,8 +67,11 @@ typedef struct rbc_config {
     int32_t device;          /* HIP device ordinal                                           */
     int32_t write_state;     /* 1: rbc_step also refreshes the float32 full-state buffer     */
     int32_t precision;       /* arithmetic of the solver: RBC_PRECISION_F64 (0, the reference's Float64, default) or
-                                RBC_PRECISION_F32 (1: float32 state and arithmetic, dim=2 only).
-                                The I/O types of the ABI do not change with it (float64 fields, float32 obs/state).  */
+                                RBC_PRECISION_F32 (1: float32 state and arithmetic) -- every path:
+                                the LDS-resident 2D kernels, the streaming 2D grids and dim=3 (rbc3D.py:229-232 hands out
+                                float32 observations anyway).  The I/O types of the ABI do not change with it (float64
+                                fields in and out, float32 obs/state; Nusselt sums stay float64); only rbc_dev_fields()
+                                exposes the solver's own element type (float for a float32 streaming / 3D handle).  */
 } rbc_config;
 
 enum { RBC_PRECISION_F64 = 0, RBC_PRECISION_F32 = 1 };

@@ -35,11 +35,10 @@ int fail(int code, const std::string &msg)
 
 }  // namespace
 
-struct rbc3_state;
-
 struct rbc_handle {
     rbc_config cfg;
-    rbc3_state *s3 = nullptr;          // streaming path (rbc3d_host.hpp): dim == 3, and dim == 2 grids without an LDS-resident kernel
+    void *s3 = nullptr;                // streaming path (rbc3d_host.hpp: host3::rbc3_state or host3f::rbc3_state): dim == 3, and dim == 2 grids without an LDS-resident kernel
+    bool s3_f32 = false;               // ... in float32 (rbc_config.precision): the state behind s3 belongs to host3f / rbc3f
     bool stream2d = false;             // dim == 2 on the streaming path (ny = 1): 2D actions, resets and outputs around the 3D stage kernels
     int obs_norm = 0, obs_clip = 0;    // rbc_set_obs_normalization
     float obs_min[5] = {0, 0, 0, 0, 0}, obs_rng[5] = {1, 1, 1, 1, 1}, obs_maxval = 1.0f;
@@ -241,7 +240,6 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     if (cfg->dim != 2 && cfg->dim != 3) return fail(RBC_ERR_INVALID, "dim must be 2 or 3");
     if (cfg->batch < 1) return fail(RBC_ERR_INVALID, "batch must be >= 1");
     if (!rbc_has_precision(cfg->precision)) return fail(RBC_ERR_INVALID, "precision must be RBC_PRECISION_F64 or RBC_PRECISION_F32");
-    if (cfg->dim == 3 && cfg->precision != RBC_PRECISION_F64) return fail(RBC_ERR_INVALID, "precision: the 3D path is float64 only");
     if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
     if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
         return fail(RBC_ERR_INVALID, "ra, pr, dt_solver, dt_control must be positive");
@@ -263,15 +261,10 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     // 2D: the LDS-resident kernel where it is built for the grid; any other float64 grid runs on the streaming kernels with
     // ny = 1 (RBC_FORCE_STREAM2D=1 sends every float64 2D handle there: the A/B partner of the resident kernel in the tests)
     bool force_stream = false;
-    { const char *e = std::getenv("RBC_FORCE_STREAM2D"); force_stream = e && e[0] == '1' && cfg->precision == RBC_PRECISION_F64; }
+    { const char *e = std::getenv("RBC_FORCE_STREAM2D"); force_stream = e && e[0] == '1'; }
     if (cfg->dim == 3) { /* streaming kernels, any grid whose horizontal slab fits the LDS FFT */ }
     else if (force_stream || !bind_grid(h, cfg->nx, cfg->nz, cfg->precision)) {
-        if (cfg->precision != RBC_PRECISION_F64) {
-            delete h;
-            return fail(RBC_ERR_INVALID, "unsupported 2D grid for precision=float32: the LDS-resident float32 kernel is built for (nx, nz) = (96,64) "
-                                         "(128,64) (64,64) (192,32); other grids run in float64 on the streaming path");
-        }
-        h->stream2d = true;
+        h->stream2d = true;                               // (float32: the rbc3f instantiation of the streaming kernels)
         h->cfg.ny = 1; h->cfg.ly = 1.0;
     }
     h->ncell = (size_t)h->nx * h->nz * (cfg->dim == 3 ? cfg->ny : 1);
@@ -325,7 +318,8 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
             CREATE_TRY(hipMalloc(&h->d_state, B * 5 * h->ncell * sizeof(float)));
             CREATE_TRY(hipMemset(h->d_state, 0, B * 5 * h->ncell * sizeof(float)));
         } else CREATE_TRY(hipMalloc(&h->d_state, B * 4 * h->ncell * sizeof(float)));
-        if (int rc = create3d(h)) { rbc_destroy(h); return rc; }
+        h->s3_f32 = (cfg->precision == RBC_PRECISION_F32);
+        if (int rc = RBC_S3(h, create3d, h)) { rbc_destroy(h); return rc; }
         h->t.assign(B, 0.0);
         h->step.assign(B, 1);
         h->inited.assign(B, 0);
@@ -361,7 +355,7 @@ int rbc_destroy(rbc_handle *h)
     if (!h) return RBC_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    destroy3d(h);
+    if (h->s3) RBC_S3(h, destroy3d, h);
     void *bufs[] = {h->d_fields, h->d_ra, h->d_tri, h->d_nu, h->d_dbg, h->d_park, h->d_celld, h->d_actions, h->d_obs, h->d_state,
                     h->d_mask, h->d_seeds, h->d_flags, h->d_stamps};
     for (void *b : bufs)
@@ -443,14 +437,7 @@ int rbc_reset(rbc_handle *h, const uint8_t *mask, const uint64_t *seeds)
     HIP_TRY(hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->s3) {
-        rbc3_state *s = h->s3;
-        if (h->stream2d)
-            hipLaunchKernelGGL(rbc3::k2s_random, grid_for((size_t)h->B * s->g.nc, 256), dim3(256), 0, h->stream, s->g, s->st[s->cur],
-                               h->d_seeds, h->d_mask, h->B);
-        else
-            hipLaunchKernelGGL(rbc3::k3_random, grid_for((size_t)h->B * s->g.nw, 256), dim3(256), 0, h->stream, s->g, s->st[s->cur],
-                               h->d_seeds, h->d_mask, h->B);
-        if (int rc = finish_reset3d(h)) return rc;
+        if (int rc = RBC_S3(h, random_reset3d, h)) return rc;
         mark_reset(h, m);
         return RBC_OK;
     }
@@ -471,19 +458,17 @@ int rbc_reset_from_arrays3(rbc_handle *h, const uint8_t *mask, const double *b, 
     HIP_TRY(hipSetDevice(h->cfg.device));
     std::vector<uint8_t> m;
     if (int rc = upload_mask(h, mask, m)) return rc;
-    rbc3_state *s = h->s3;
-    const size_t nc = s->g.nc, nw = s->g.nw;
-    h->stage.resize(s->g.env_stride);
+    const size_t nc = h->ncell, nw = RBC_S3(h, faces3d, h);
+    h->stage.resize(RBC_S3(h, env_stride3d, h));
     for (int e = 0; e < h->B; ++e) {
         if (!m[e]) continue;
         std::memcpy(h->stage.data(), b + (size_t)e * nc, nc * sizeof(double));
         std::memcpy(h->stage.data() + nc, u + (size_t)e * nc, nc * sizeof(double));
         std::memcpy(h->stage.data() + 2 * nc, v + (size_t)e * nc, nc * sizeof(double));
         std::memcpy(h->stage.data() + 3 * nc, w + (size_t)e * nw, nw * sizeof(double));
-        HIP_TRY(hipMemcpy(s->st[s->cur] + (size_t)e * s->g.env_stride, h->stage.data(), s->g.env_stride * sizeof(double),
-                          hipMemcpyHostToDevice));
+        if (int rc = RBC_S3(h, put_env3d, h, e, h->stage.data())) return rc;
     }
-    if (int rc = finish_reset3d(h)) return rc;
+    if (int rc = RBC_S3(h, finish_reset3d, h)) return rc;
     mark_reset(h, m);
     return RBC_OK;
 }
@@ -498,17 +483,15 @@ int rbc_reset_from_arrays(rbc_handle *h, const uint8_t *mask, const double *b, c
     if (int rc = upload_mask(h, mask, m)) return rc;
     const size_t nc = h->ncell, nw = nc + h->nx;
     if (h->stream2d) {                                  // streaming layout [b | u | v = 0 | w]
-        rbc3_state *s = h->s3;
-        h->stage.assign(s->g.env_stride, 0.0);
+        h->stage.assign(RBC_S3(h, env_stride3d, h), 0.0);
         for (int e = 0; e < h->B; ++e) {
             if (!m[e]) continue;
             std::memcpy(h->stage.data(), b + (size_t)e * nc, nc * sizeof(double));
             std::memcpy(h->stage.data() + nc, u + (size_t)e * nc, nc * sizeof(double));
             std::memcpy(h->stage.data() + 3 * nc, w + (size_t)e * nw, nw * sizeof(double));
-            HIP_TRY(hipMemcpy(s->st[s->cur] + (size_t)e * s->g.env_stride, h->stage.data(), s->g.env_stride * sizeof(double),
-                              hipMemcpyHostToDevice));
+            if (int rc = RBC_S3(h, put_env3d, h, e, h->stage.data())) return rc;
         }
-        if (int rc = finish_reset3d(h)) return rc;
+        if (int rc = RBC_S3(h, finish_reset3d, h)) return rc;
         mark_reset(h, m);
         return RBC_OK;
     }
@@ -545,7 +528,7 @@ int rbc_step_dev(rbc_handle *h, const float *actions_dev)
     if (!actions_dev) return fail(RBC_ERR_INVALID, "null actions");
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->s3) {
-        if (int rc = step3d(h, actions_dev, h->nsub, h->dt_solver_eff, h->dt_last, true)) return rc;
+        if (int rc = RBC_S3(h, step3d, h, actions_dev, h->nsub, h->dt_solver_eff, h->dt_last, true)) return rc;
         advance_clocks(h);
         return RBC_OK;
     }
@@ -600,7 +583,7 @@ int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const doubl
     }
     for (int c = 0; c < nch; ++c) { h->obs_min[c] = (float)min_vals[c]; h->obs_rng[c] = (float)(max_vals[c] - min_vals[c]); }
     h->obs_norm = nch; h->obs_clip = clip ? 1 : 0; h->obs_maxval = (float)maxval;
-    if (h->s3) drop_graphs3d(h);          // a captured env-step carries the old parameters as kernel arguments
+    if (h->s3) RBC_S3(h, drop_graphs3d, h);          // a captured env-step carries the old parameters as kernel arguments
     return RBC_OK;
 }
 
@@ -678,13 +661,10 @@ int rbc_get_fields3(rbc_handle *h, double *b, double *u, double *v, double *w)
     if (!is3d(h)) return fail(RBC_ERR_INVALID, "rbc_get_fields3 needs a dim=3 handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    rbc3_state *s = h->s3;
-    const size_t nc = s->g.nc, nw = s->g.nw, pitch = s->g.env_stride * sizeof(double);
-    const double *base = s->st[s->cur];
-    if (b) HIP_TRY(hipMemcpy2D(b, nc * sizeof(double), base, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
-    if (u) HIP_TRY(hipMemcpy2D(u, nc * sizeof(double), base + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
-    if (v) HIP_TRY(hipMemcpy2D(v, nc * sizeof(double), base + 2 * nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
-    if (w) HIP_TRY(hipMemcpy2D(w, nw * sizeof(double), base + 3 * nc, pitch, nw * sizeof(double), h->B, hipMemcpyDeviceToHost));
+    double *outs[4] = {b, u, v, w};
+    for (int f = 0; f < 4; ++f)
+        if (outs[f])
+            if (int rc = RBC_S3(h, get_field3d, h, f, outs[f])) return rc;
     return RBC_OK;
 }
 
@@ -695,12 +675,10 @@ int rbc_get_fields(rbc_handle *h, double *b, double *u, double *w)
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->stream2d) {
-        rbc3_state *s = h->s3;
-        const size_t nc = s->g.nc, nw = s->g.nw, pitch = s->g.env_stride * sizeof(double);
-        const double *base = s->st[s->cur];
-        if (b) HIP_TRY(hipMemcpy2D(b, nc * sizeof(double), base, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
-        if (u) HIP_TRY(hipMemcpy2D(u, nc * sizeof(double), base + nc, pitch, nc * sizeof(double), h->B, hipMemcpyDeviceToHost));
-        if (w) HIP_TRY(hipMemcpy2D(w, nw * sizeof(double), base + 3 * nc, pitch, nw * sizeof(double), h->B, hipMemcpyDeviceToHost));
+        double *outs[4] = {b, u, nullptr, w};              // streaming layout [b | u | v = 0 | w]
+        for (int f = 0; f < 4; ++f)
+            if (outs[f])
+                if (int rc = RBC_S3(h, get_field3d, h, f, outs[f])) return rc;
         return RBC_OK;
     }
     const size_t nc = h->ncell, nw = nc + h->nx, pitch = h->env_stride * sizeof(double);
@@ -754,7 +732,7 @@ void *rbc_dev_obs(rbc_handle *h) { return h ? h->d_obs : nullptr; }
 void *rbc_dev_state(rbc_handle *h) { return h ? h->d_state : nullptr; }
 void *rbc_dev_nusselt(rbc_handle *h) { return h ? h->d_nu : nullptr; }
 void *rbc_dev_flags(rbc_handle *h) { return h ? h->d_flags : nullptr; }
-void *rbc_dev_fields(rbc_handle *h) { return h ? (h->s3 ? (void *)h->s3->st[h->s3->cur] : (void *)h->d_fields) : nullptr; }
+void *rbc_dev_fields(rbc_handle *h) { return h ? (h->s3 ? RBC_S3(h, dev_fields3d, h) : (void *)h->d_fields) : nullptr; }
 
 int rbc_set_profiling(rbc_handle *h, int max_launches)
 {
@@ -848,27 +826,9 @@ int rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, doubl
     if (!is3d(h)) return fail(RBC_ERR_INVALID, "needs a dim=3 handle");
     if (!actions || !gu || !gv || !gw || !gb) return fail(RBC_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    rbc3_state *s = h->s3;
-    const rbc3::Geo3 &g = s->g;
-    const int B = h->B;
-    const size_t nc = g.nc;
-    if (!s->dbg) HIP_TRY(hipMalloc(&s->dbg, (size_t)B * 4 * nc * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)B * g.heaters * g.heaters * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rbc3::k3_preprocess, dim3(B), dim3(64), 0, h->stream, g, h->d_actions, s->actT, 0);
-    double *cur = s->st[s->cur];
-    hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
-    const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
-    hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-    hipLaunchKernelGGL(rbc3::k3_tendency<1>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-    hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-    hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    const size_t pitch = 4 * nc * sizeof(double);
-    double *outs[4] = {gu, gv, gw, gb};
-    for (int q = 0; q < 4; ++q)
-        HIP_TRY(hipMemcpy2D(outs[q], nc * sizeof(double), s->dbg + q * nc, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
-    return RBC_OK;
+    HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * actions_per_env(h) * sizeof(float), hipMemcpyHostToDevice));
+    double *const outs[4] = {gu, gv, gw, gb};
+    return RBC_S3(h, debug_tendencies3d, h, outs);
 }
 
 int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double *gu, double *gw)
@@ -878,26 +838,9 @@ int rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, double
     if (!actions || !gb || !gu || !gw) return fail(RBC_ERR_INVALID, "null argument");
     if (h->stream2d) {                     // the cell-per-thread tendency kernels on the ny = 1 state
         HIP_TRY(hipSetDevice(h->cfg.device));
-        rbc3_state *s = h->s3;
-        const rbc3::Geo3 &g = s->g;
-        const int B = h->B;
-        const size_t nc = g.nc;
-        if (!s->dbg) HIP_TRY(hipMalloc(&s->dbg, (size_t)B * 4 * nc * sizeof(double)));
-        HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)B * g.heaters * sizeof(float), hipMemcpyHostToDevice));
-        wall3d(h, whole_batch(h), h->d_actions, 0);
-        double *cur = s->st[s->cur];
-        hipLaunchKernelGGL(rbc3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, h->stream, g, cur, s->phy, B);
-        const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
-        hipLaunchKernelGGL(rbc3::k3_tendency<0>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-        hipLaunchKernelGGL(rbc3::k3_tendency<2>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-        hipLaunchKernelGGL(rbc3::k3_tendency<3>, gc, bc, 0, h->stream, g, cur, cur, s->gm, s->phy, s->actT, h->d_ra, 0.0, 1.0, 0.0, B, s->dbg);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        const size_t pitch = 4 * nc * sizeof(double);
-        HIP_TRY(hipMemcpy2D(gb, nc * sizeof(double), s->dbg + 3 * nc, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy2D(gu, nc * sizeof(double), s->dbg, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy2D(gw, nc * sizeof(double), s->dbg + 2 * nc, pitch, nc * sizeof(double), B, hipMemcpyDeviceToHost));
-        return RBC_OK;
+        HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * actions_per_env(h) * sizeof(float), hipMemcpyHostToDevice));
+        double *const outs[4] = {gu, nullptr, gw, gb};
+        return RBC_S3(h, debug_tendencies3d, h, outs);
     }
     if (h->lanes != 1) return fail(RBC_ERR_INVALID, "rbc_debug_tendencies: not available on the packed float32 kernel (RBC_F32_SCALAR=1 selects the scalar one)");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -935,7 +878,7 @@ int rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt)
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->s3) {
         HIP_TRY(hipMemcpy(h->d_actions, actions, (size_t)h->B * actions_per_env(h) * sizeof(float), hipMemcpyHostToDevice));
-        if (int rc = step3d(h, h->d_actions, nsub, dt, dt, false)) return rc;
+        if (int rc = RBC_S3(h, step3d, h, h->d_actions, nsub, dt, dt, false)) return rc;
         HIP_TRY(hipStreamSynchronize(h->stream));
         return RBC_OK;
     }

@@ -377,9 +377,10 @@ class NativeSim3D:
     """A batch of B 3D envs on one GPU (rbc_sim3D_api.jl semantics; array shapes (nz, ny, nx))."""
 
     def __init__(self, batch=1, device=0, shape=(16, 32, 32), domain=(2.0, 4 * np.pi, 4 * np.pi), ra=2500.0, pr=0.7,
-                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01, random_kick=None):
+                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01, random_kick=None, precision=0):
         self.lib = load_library()
         cfg = default_config()
+        cfg.precision = int(PRECISIONS.get(precision, precision))
         nz, ny, nx = shape
         lz, ly, lx = domain
         cfg.dim, cfg.nx, cfg.ny, cfg.nz = 3, int(nx), int(ny), int(nz)

@@ -314,12 +314,14 @@ def test_heater_profile_with_active_blend_zones_matches_oracle(native, oracle):
 
 
 def test_unsupported_grids_fail_loudly(native):
-    """float64 grids without an LDS-resident kernel run on the streaming path (tests/test_gpu_stream2d.py); what is left to
-    refuse: grids below 8 cells, and float32 (resident kernels only) on a grid it is not built for."""
-    for nx, nz, prec in ((4, 64, 0), (96, 4, 0), (100, 64, 1), (96, 40, 1), (256, 64, 1)):
+    """Grids without an LDS-resident kernel run on the streaming path in either precision (tests/test_gpu_stream2d.py); what is
+    left to refuse: grids below 8 cells."""
+    for nx, nz, prec in ((4, 64, 0), (96, 4, 0), (4, 64, 1)):
         with pytest.raises(native.RbcError) as e:
             native.NativeSim(batch=1, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=4, precision=prec)
         assert "unsupported 2D grid" in str(e.value)
+    for nx, nz in ((100, 64), (96, 40), (256, 64)):            # float32 off the resident kernels' grid list: the rbc3f streaming kernels
+        native.NativeSim(batch=1, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=4, precision=1).close()
 
 
 # ---------------------------------------------------------------------------------------------

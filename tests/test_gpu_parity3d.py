@@ -199,6 +199,91 @@ def test_config4_shape_matches_oracle(native, o3):
     assert np.allclose(t, 0.5) and np.all(s == 2)
 
 
+def test_float32_3d_within_stated_tolerances_of_the_float64_oracle(native, o3):
+    """rbc_config.precision = float32 on the 3D path (the rbc3f instantiation of every streaming kernel; rbc3D.py:229-232 hands
+    out float32 observations anyway) at BASELINE.json configs[4]'s shape, from a DEVELOPED convecting state, one env-step of 13
+    substeps.  Stated tolerances against the float64 oracle on the identical initial fields (float32-rounded on upload):
+    tendencies 2e-5 of their maximum, b 1e-6 rel-L2, u, v, w 1e-4, Nusselt number 1e-5; divergence at float32 round-off.  The
+    deferred vertical correction (the float32 default) and the separate pass agree to float32 round-off."""
+    shape, ra, B = (32, 48, 48), 1e4, 2
+    gen = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, random_kick=0.1)
+    gen.reset(np.array([11, 12], dtype=np.uint64))
+    rng = np.random.default_rng(4)
+    for n in range(400):
+        assert gen.step(rng.uniform(-1, 1, (B, 8, 8)).astype(np.float32))
+        if n >= 60 and np.all(gen.get_nusselt() > 1.5):
+            break
+    ics = gen.get_fields()
+    gen.close()
+    act = rng.uniform(-1, 1, (B, 8, 8)).astype(np.float32)
+    sim = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, precision="f32")
+    sim.reset_from_arrays(*ics)
+    g = sim.debug_tendencies(act)
+    orcs = []
+    for e in range(B):
+        o = o3.Oracle3D(ra=ra, shape=shape, dt_control=0.125, dt_solver=0.01)
+        o.reset_from_arrays(*[x[e] for x in ics])
+        o.set_action(act[e]); o.update_state()
+        go = o.tendencies()
+        for f in "uvwb":
+            assert np.abs(g[f][e] - go[f]).max() < 2e-5 * max(np.abs(go[f]).max(), 1.0), f
+        orcs.append(o)
+    assert sim.step(act)
+    fields, nus, st = sim.get_fields(), sim.get_nusselt(), sim.get_state()
+    dx, dz = 4 * np.pi / 48, 2.0 / 32
+    for e, o in enumerate(orcs):
+        assert o.step(act[e])
+        errs = [rel_l2(x[e], y) for x, y in zip(fields, o.fields())]
+        assert errs[0] < 1e-6 and max(errs[1:]) < 1e-4, errs
+        assert abs(nus[e] - o.nusselt()) < 1e-5 * abs(o.nusselt())
+        assert np.allclose(st[e], o.state(), rtol=1e-4, atol=1e-5)
+        b, u, v, w = [x[e] for x in fields]
+        div = (np.roll(u, -1, axis=2) - u) / dx + (np.roll(v, -1, axis=1) - v) / dx + (w[1:] - w[:-1]) / dz
+        assert np.abs(div).max() < 2e-5 * np.abs(u).max() / dx
+    t, s = sim.get_info()
+    assert np.allclose(t, 0.5) and np.all(s == 2)
+    sim.close()
+    import os
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["RBC_DEFER_W"] = flag
+        try:
+            s2 = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, precision="f32")
+            s2.reset_from_arrays(*ics)
+            assert s2.step(act) and s2.step(act)
+            outs.append(s2.get_fields())
+            s2.close()
+        finally:
+            del os.environ["RBC_DEFER_W"]
+    for x, y in zip(*outs):
+        assert rel_l2(x, y) < 2e-6
+
+
+def test_float32_3d_flowstats_statistics(native):
+    """The reference's flow-statistics protocol (pin P4, flowstats_ra.py:27-36) in float32: last-100-step mean Nusselt numbers
+    of all 14 Rayleigh numbers within the same bars as the float64 run (5 %, 12 % just above onset), Nu[0] at Ra = 500."""
+    ref = {500: 1.368, 750: 1.513, 1000: 1.497, 1500: 1.668, 2000: 1.762, 4000: 2.128, 8000: 2.411, 16000: 2.851,
+           32000: 3.453, 64000: 4.232, 128000: 5.233, 256000: 6.422, 512000: 7.886, 1000000: 9.212}
+    ras = sorted(ref)
+    seeds = 2
+    B = seeds * len(ras)
+    sim = native.NativeSim3D(batch=B, shape=(32, 64, 64), dt_control=0.25, dt_solver=0.005, precision="f32")
+    sim.set_rayleigh(np.tile(np.array(ras, dtype=np.float64), seeds))
+    sim.reset(np.arange(B, dtype=np.uint64) + 2024)
+    zero = np.zeros((B, 8, 8), np.float32)
+    nus = []
+    for n in range(300):
+        assert sim.step(zero)
+        nus.append(sim.get_nusselt().copy())
+    nus = np.array(nus)
+    assert abs(nus[0, 0] - 1.0) < 1e-4
+    means = nus[200:].mean(0).reshape(seeds, len(ras)).mean(0)
+    for j, ra in enumerate(ras):
+        tol = 0.12 if 750 <= ra <= 1500 else 0.05
+        assert abs(means[j] - ref[ra]) < tol * ref[ra], (ra, means[j], ref[ra])
+    sim.close()
+
+
 def test_fast_fft_sizes(native, o3):
     """48 = 6x8 and 64 = 8x8 take the register-blocked slab FFT (dft6 / dft8 x dft8); the other tests
     run 32 = 4x8 and the generic 24 = 4x6 path."""
