@@ -249,7 +249,7 @@ def run_3d(ctx, B, K, W, ra, precision="f64"):
     alg = sim.algorithmic_bytes_per_env_step() * B
     avg = float(np.mean(ms)) if len(ms) else float("nan")
     ach = alg / (avg * 1e-3) / 1e9
-    prof, src = latest_profile("*_3d_summary.json", {"dim": 3, "batch": B, "ra": ra, "precision": precision})
+    prof, src = latest_profile("*_3d*_summary.json", {"dim": 3, "batch": B, "ra": ra, "precision": precision, "groups": None})
     traffic = prof.get("hbm_traffic_bytes_per_env_step_batch") if prof else None
     sim.close()
     return {
@@ -422,7 +422,7 @@ def main():
                local_rank=local_rank, world=world, barrier=barrier)
     K, W = args.steps, args.warmup
     if args.dim == 3:
-        out = run_3d(ctx, args.batch or 32, K, W, args.ra)
+        out = run_3d(ctx, args.batch or 32, K, W, args.ra, args.precision)
         if rank == 0:
             out["cpu_baseline"] = cpu
             print(json.dumps(out))
@@ -565,8 +565,17 @@ def main():
                 s2.reset(sharding.env_seeds(1234, 0, B))
                 s2.step_dev(actions.data_ptr())
                 e2 = timed_loop(torch, dev, barrier, lambda n: s2.step_dev(actions.data_ptr() + ((1 + n) % (K + W)) * stride), 3)
+                alg2 = s2.algorithmic_bytes_per_env_step() * B
+                p2, p2src = latest_profile("*_stream2d_128x64_summary.json", {"dim": 2, "batch": B, "nx": 128, "nz": 64, "precision": "f64"})
+                tr2 = p2.get("hbm_traffic_bytes_per_env_step_batch") if p2 else None
                 extra["streaming_2d_128x64"] = {"value": B * 3 / e2, "unit": "env-steps/s", "ms_per_step": e2 / 3 * 1e3, "steps": 3, "warmup": 1,
-                                                "algorithmic_gbs": s2.algorithmic_bytes_per_env_step() * B * 3 / e2 / 1e9,
+                                                "algorithmic_gbs": alg2 * 3 / e2 / 1e9,
+                                                "roofline": {"bound": "hbm", "achieved": alg2 * 3 / e2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                             "frac": alg2 * 3 / e2 / 1e9 / HBM_PEAK_GBS, "traffic": tr2, "traffic_source": p2src,
+                                                             "traffic_over_algorithmic": (tr2 / alg2) if tr2 else None,
+                                                             "measured_hbm_gbs": (tr2 * 3 / e2 / 1e9) if tr2 else None,
+                                                             "algorithmic_bytes_per_launch": alg2,
+                                                             "note": "one 'launch' = one env-step of the batch (150 stages x [tile kernel + one-kernel projection] on three stream chains)"},
                                                 "nan_envs": int(s2.get_flags().sum()), "mean_nusselt_state": float(np.mean(s2.get_nusselt()[0]))}
                 s2.close()
             except Exception as e:                       # an extra must never take the contract line down with it

@@ -57,6 +57,9 @@ enum Mode : int { MODE_STEP = 0, MODE_PROJECT = 1, MODE_RANDOM = 2, MODE_TENDENC
 #define RBC_PW_W 3
 #define RBC_PW_I 1
 #endif
+#ifndef RBC_EXPERIMENT_NOPHYPRE
+#define RBC_EXPERIMENT_NOPHYPRE 0   // timing experiment only (WRONG numerics): drops the hydrostatic pre-pass (chunk totals of the column scan)
+#endif
 #ifndef RBC_EXPERIMENT_NOG0
 #define RBC_EXPERIMENT_NOG0 0   // timing experiment only (WRONG numerics): drops the G^- registers
 #endif
@@ -917,6 +920,9 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
             //         = -dz * sum_{k'>=k} mean(db[k'], db[k'+1]),  db[k] = b[i,k]-b[i-1,k].
             // Pre-pass: the chunk totals; the u pass below walks DOWN its chunk and accumulates.
             real db_top;   // db at the first row above the chunk (halo row for the top chunk)
+#if RBC_EXPERIMENT_NOPHYPRE
+            db_top = real(0); scr[c * NX + i] = real(0);
+#else
             {
                 {   // branch-free: the top chunk takes the Value-BC halo row, the others the row above
                     const real cN = cc0[(CZ - 1) * RS + FB], cM = cm1[(CZ - 1) * RS + FB];
@@ -937,6 +943,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
                 }
                 scr[c * NX + i] = acc;
             }
+#endif
             STAMP(15);
             real g0b[CZ], g0w[CZ];
             lds_barrier();

@@ -30,4 +30,20 @@ fi
 run trace3d --stats -- $B3 && grep '^{"metric"' "$OUT/trace3d.log" > "$OUT/bench_trace3d.log"
 run pmc_fetch3d --pmc FETCH_SIZE -- $B3
 run pmc_write3d --pmc WRITE_SIZE -- $B3
+# one chain on the handle's stream: per-kernel times and counters without the other chains' kernels in between
+export RBC_3D_GROUPS=1
+run trace3d_g1 --stats -- $B3 && grep '^{"metric"' "$OUT/trace3d_g1.log" > "$OUT/bench_trace3d_g1.log"
+run pmc_fetch3d_g1 --pmc FETCH_SIZE -- $B3
+run pmc_write3d_g1 --pmc WRITE_SIZE -- $B3
+unset RBC_3D_GROUPS
+# the float32 instantiation of the same kernels (bench.py --precision f32 --dim 3)
+B3F="$B3 --precision f32"
+run trace3d_f32 --stats -- $B3F && grep '^{"metric"' "$OUT/trace3d_f32.log" > "$OUT/bench_trace3d_f32.log"
+run pmc_fetch3d_f32 --pmc FETCH_SIZE -- $B3F
+run pmc_write3d_f32 --pmc WRITE_SIZE -- $B3F
+# streaming 2D at 128x64 (no LDS-resident float64 kernel): 1 warm-up + 3 env-steps of 1024 envs
+S2="python3 $ROOT/scripts/stream2d_timing.py 1024 3 128 64"
+run trace_s2d --stats -- $S2
+run pmc_fetch_s2d --pmc FETCH_SIZE -- $S2
+run pmc_write_s2d --pmc WRITE_SIZE -- $S2
 ls "$OUT"

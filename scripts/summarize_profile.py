@@ -120,32 +120,50 @@ if ksf:
     json.dump(summf, open(f"{out}/{tag}_f32_summary.json", "w"), indent=1)
     print(json.dumps({k: v for k, v in summf.items() if k != "bench_line_under_profiler"}, indent=1))
 
-# ---------------------------------------------------------------- 3D configs[4] workload
-ks3 = one(f"{src}/trace3d/*/*_kernel_stats.csv")
-if ks3:
-    shutil.copy(ks3, f"{out}/{tag}_3d_kernel_stats.csv")
-    line3 = bench_line(f"{src}/bench_trace3d.log")
-    steps = (line3 or {}).get("steps", 5) + (line3 or {}).get("warmup", 2)
+# ---------------------------------------------------------------- streaming paths: 3D configs[4] (default chains, one chain, float32), streaming 2D
+def streaming(trace, fetch, write, dst, key, steps_default, bench_log, what):
+    ks3 = one(f"{src}/{trace}/*/*_kernel_stats.csv")
+    if not ks3:
+        return
+    shutil.copy(ks3, f"{out}/{tag}_{dst}_kernel_stats.csv")
+    line3 = bench_line(f"{src}/{bench_log}") if bench_log else None
+    steps = ((line3 or {}).get("steps", 0) + (line3 or {}).get("warmup", 0)) or steps_default
     per_kernel = {}
     for r in csv.DictReader(open(ks3)):
-        if "rbc3::" in r["Name"]:
+        if "rbc3" in r["Name"]:
             per_kernel[r["Name"].split("(")[0].replace("void ", "")] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                                                        "total_ms": float(r["TotalDurationNs"]) / 1e6}
     tot = {}
-    for name, ctr in (("pmc_fetch3d", "FETCH_SIZE"), ("pmc_write3d", "WRITE_SIZE")):
-        c = counters(name, "rbc3::").get(ctr, {})
+    for name, ctr in ((fetch, "FETCH_SIZE"), (write, "WRITE_SIZE")):
+        c = counters(name, "rbc3").get(ctr, {})
         for kern, vals in c.items():
             k = kern.split("(")[0].replace("void ", "")
             per_kernel.setdefault(k, {})[f"{ctr}_KB_per_call"] = sum(vals) / len(vals)
             per_kernel[k][f"{ctr}_KB_total"] = sum(vals)
-        tot[ctr] = sum(x for vals in c.values() for x in vals)
-    summ3 = {"workload_key": {"dim": 3, "batch": 32, "ra": 1e4}, "env_steps_profiled": steps, "kernels": per_kernel,
-             "note": "FETCH_SIZE / WRITE_SIZE in KB, raw counter values (separate --pmc passes); totals cover reset + all profiled env-steps of the batch"}
+        if c:
+            tot[ctr] = sum(x for vals in c.values() for x in vals)
+    summ3 = {"workload_key": key, "what": what, "env_steps_profiled": steps, "kernels": per_kernel,
+             "kernel_time_ms_per_env_step_batch": sum(k.get("total_ms", 0.0) for k in per_kernel.values()) / steps,
+             "note": "FETCH_SIZE / WRITE_SIZE in KB, raw counter values (separate --pmc passes); totals cover reset + all profiled env-steps of the batch; "
+                     "under rocprofv3 concurrent stream chains serialise, so per-kernel times are those of the kernels alone, not of the overlapped run"}
     if len(tot) == 2:
         summ3["hbm_traffic_bytes_per_env_step_batch"] = (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps
         summ3["fetch_bytes_per_env_step_batch"] = tot["FETCH_SIZE"] * 1024 / steps
         summ3["write_bytes_per_env_step_batch"] = tot["WRITE_SIZE"] * 1024 / steps
     if line3:
         summ3["bench_line_under_profiler"] = line3
-    json.dump(summ3, open(f"{out}/{tag}_3d_summary.json", "w"), indent=1)
-    print(json.dumps({k: v for k, v in summ3.items() if k not in ("bench_line_under_profiler",)}, indent=1)[:3000])
+        alg = (line3.get("roofline") or {}).get("algorithmic_bytes_per_launch")
+        if alg and "hbm_traffic_bytes_per_env_step_batch" in summ3:
+            summ3["traffic_over_algorithmic"] = summ3["hbm_traffic_bytes_per_env_step_batch"] / alg
+    json.dump(summ3, open(f"{out}/{tag}_{dst}_summary.json", "w"), indent=1)
+    print(dst, json.dumps({k: v for k, v in summ3.items() if k not in ("bench_line_under_profiler", "kernels")}, indent=1)[:1500])
+
+
+streaming("trace3d", "pmc_fetch3d", "pmc_write3d", "3d", {"dim": 3, "batch": 32, "ra": 1e4, "precision": "f64"}, 7, "bench_trace3d.log",
+          "configs[4] float64, default env groups (four stream chains, one graph)")
+streaming("trace3d_g1", "pmc_fetch3d_g1", "pmc_write3d_g1", "3d_g1", {"dim": 3, "batch": 32, "ra": 1e4, "precision": "f64", "groups": 1}, 7, "bench_trace3d_g1.log",
+          "configs[4] float64, RBC_3D_GROUPS=1: one chain on the handle's stream (clean per-kernel counters)")
+streaming("trace3d_f32", "pmc_fetch3d_f32", "pmc_write3d_f32", "3d_f32", {"dim": 3, "batch": 32, "ra": 1e4, "precision": "f32"}, 7, "bench_trace3d_f32.log",
+          "configs[4] float32 (rbc3f kernels, deferred w correction)")
+streaming("trace_s2d", "pmc_fetch_s2d", "pmc_write_s2d", "stream2d_128x64", {"dim": 2, "batch": 1024, "nx": 128, "nz": 64, "precision": "f64"}, 4, None,
+          "streaming 2D, 128x64 float64, B = 1024, 1 warm-up + 3 env-steps (scripts/stream2d_timing.py 1024 3 128 64)")
