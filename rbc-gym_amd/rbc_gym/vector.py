@@ -216,9 +216,10 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
     def __init__(self, num_envs=1, rayleigh_number=2500, prandtl_number=0.7, domain=(2, 4 * np.pi, 4 * np.pi),
                  state_shape=(16, 32, 32), temperature_difference=(1, 2), heater_segments=8, heater_limit=0.9,
                  heater_duration=0.125, episode_length=300, dt_solver=0.01, use_gpu=True, checkpoint=None, checkpoint_idx=None,
-                 render_mode=None, device=0, devices=None, **_ignored):
+                 render_mode=None, device=0, devices=None, precision="f64", **_ignored):
         from .envs.rbc3D import build_spaces3d
         self.num_envs = int(num_envs)
+        self.precision = precision                                   # "f32": the float32 instantiation of the 3D kernels (1.5x at configs[4])
         self.ra, self.pr = rayleigh_number, prandtl_number
         self.dim = 3
         self.domain, self.state_shape = list(domain), list(state_shape)
@@ -232,7 +233,7 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
         def make(count, dev):
             return _native.NativeSim3D(batch=count, device=dev, shape=tuple(state_shape), domain=tuple(domain), ra=ra0,
                                        pr=float(prandtl_number), t_diff=tuple(temperature_difference), heaters=heater_segments,
-                                       heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver)
+                                       heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver, precision=precision)
         self.devices = None if devices is None else [int(d) for d in devices]
         self.sim = make(self.num_envs, device) if self.devices is None else ShardedSim(make, self.num_envs, self.devices)
         if np.ndim(rayleigh_number) > 0:

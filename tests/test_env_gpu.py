@@ -267,6 +267,33 @@ def test_rayleigh_sweep_statistics_match_reference_data(golden_dir):
         assert lo - 0.25 * (hi - lo) - 0.2 < nus[j].mean() < hi + 0.25 * (hi - lo) + 0.2, (ra, nus[j].mean(), lo, hi)
 
 
+def test_3d_env_in_float32_keeps_the_contract(gym):
+    """`precision="f32"` on the 3D env and its vector env: the float32 instantiation of the 3D kernels behind the same spaces,
+    info keys, clocks and autoreset; observations within float32 round-off of the float64 env over two control intervals."""
+    ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
+    outs = []
+    for prec in ("f64", "f32"):
+        env = gym.make(ID3, state_shape=(16, 32, 32), heater_duration=0.0625, episode_length=0.5, precision=prec)
+        obs, info = env.reset(seed=4)
+        assert obs.shape == (4, 16, 32, 32) and obs.dtype == np.float32 and info["t"] == 0.0 and info["step"] == 1
+        a = np.random.default_rng(1).uniform(-1, 1, (8, 8)).astype(np.float32)
+        obs, r, term, trunc, info = env.step(a)
+        obs, r, term, trunc, info = env.step(a)
+        assert r == -info["nusselt"] and info["t"] == 0.5 and trunc and env.unwrapped.precision == prec
+        outs.append((obs, info["nusselt"]))
+        env.close()
+    (o64, n64), (o32, n32) = outs
+    assert np.abs(o32[0] - o64[0]).max() < 2e-6 and np.abs(o32[1:] - o64[1:]).max() < 1e-5 and abs(n32 - n64) < 1e-5 * abs(n64)
+    venv = gym.make_vec(ID3, num_envs=4, state_shape=(16, 32, 32), heater_duration=0.0625, episode_length=0.25, precision="f32")
+    o, i = venv.reset(seed=7)
+    assert o.shape == (4, 4, 16, 32, 32) and o.dtype == np.float32
+    o, r, term, trunc, i = venv.step(np.zeros((4, 8, 8), np.float32))
+    assert np.all(trunc) and np.all(i["step"] == 2) and np.isfinite(r).all()
+    o, r, term, trunc, i = venv.step(np.zeros((4, 8, 8), np.float32))                   # NEXT_STEP autoreset
+    assert np.all(i["step"] == 1) and np.all(i["t"] == 0.0)
+    venv.close()
+
+
 def test_3d_env_contract(gym, tmp_path):
     """rbc3D.py: spaces, info keys {t, step, nusselt}, time in free-fall units, full-state observation."""
     ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
