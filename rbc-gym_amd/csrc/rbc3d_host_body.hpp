@@ -421,14 +421,14 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
         auto enough = [&](int kt) { return g.nz % kt == 0 && 2 * (size_t)B * (g.nz / kt) >= 256; };
         shape = enough(16) ? 5 : (enough(8) ? 6 : 7);
     }
-    // The vertical half of a stage's projection deferred into the next stage's tile kernels (tile_correct_w) instead of the separate
-    // k3_correct_w pass: one launch and 1.2 MB per env and stage less.  Parity-green in both precisions
-    // (tests/test_gpu_parity3d.py).  float32: ON -- the tile kernel has register headroom (154 VGPRs, no spill) and configs[4] gains
-    // 9 % (8.15k -> 8.87k env-steps/s).  float64: OFF -- the two phi planes held across a level push the 168-register kernel from
-    // 6 to 20 spilled VGPRs and the step is 18 % SLOWER (4.82k against 5.90k).  RBC_DEFER_W=0/1 overrides either default.
-    const bool defer_default = std::is_same<real, float>::value;
+    // RBC_DEFER_W=1: the vertical half of a stage's projection deferred into the next stage's tile kernels (tile_correct_w) instead
+    // of the separate k3_correct_w pass: one launch and 1.2 MB per env and stage less.  Parity-green in both precisions
+    // (tests/test_gpu_parity3d.py) and a measured LOSS in both (configs[4], three A/B repeats on one box): float64 4.84k against
+    // 5.95k env-steps/s (the two phi planes held across a level push the (w, b) body from 6 to 26 spilled VGPRs at the
+    // 168-register cap), float32 8.97k against 9.11k (no spill, but the extra loads and selects in the tile kernels cost more than
+    // the pass they replace).  Off by default; kept as a tested knob.
     const bool can_defer = shape >= 1 && shape <= 4 && !h->stream2d && g.nz % 2 == 0 && !h->no_pair &&
-                           ([&] { const char *e = std::getenv("RBC_DEFER_W"); return e ? e[0] == '1' : defer_default; }());
+                           ([] { const char *e = std::getenv("RBC_DEFER_W"); return e && e[0] == '1'; }());
     const real *phi_g = s->phi + (size_t)q.e0 * g.nc;
     bool pending = false;                                      // cur holds w* of the previous stage, its phi / dts below
     double dts_pending = 0.0;

@@ -1,4 +1,5 @@
-for v in "" "RBC_DEFER_W=1" "RBC_HIP_LIB=rbc-gym_amd/lib/librbc_hip_w6.so" "RBC_HIP_LIB=rbc-gym_amd/lib/librbc_hip_w4.so"; do
+# A/B timing of the 3D tile-kernel variants at configs[4] (B = 32, graph replay): RBC_TILE_SPLIT x RBC_DEFER_W x precision
+for v in "RBC_TILE_SPLIT=0 RBC_DEFER_W=0" "RBC_TILE_SPLIT=0 RBC_DEFER_W=1" "RBC_TILE_SPLIT=1 RBC_DEFER_W=0" "RBC_TILE_SPLIT=1 RBC_DEFER_W=1"; do
   echo "== $v"; env $v python - <<'PY'
 import os, sys, time
 import numpy as np
@@ -9,11 +10,12 @@ for prec in (0, 1):
     B=32
     sim = _native.NativeSim3D(batch=B, shape=(32, 48, 48), ra=1e4, precision=prec)
     sim.reset(np.arange(B, dtype=np.uint64) + 1234)
-    act = (torch.rand((B,8,8), device="cuda")*2-1).contiguous(); torch.cuda.synchronize()
+    g=torch.Generator(device="cuda"); g.manual_seed(1)
+    act = (torch.rand((B,8,8), device="cuda", generator=g)*2-1).contiguous(); torch.cuda.synchronize()
     for _ in range(3): sim.step_dev(act.data_ptr())
     sim.synchronize(); t0=time.perf_counter()
-    for _ in range(20): sim.step_dev(act.data_ptr())
-    sim.synchronize(); dt=(time.perf_counter()-t0)/20
+    for _ in range(60): sim.step_dev(act.data_ptr())
+    sim.synchronize(); dt=(time.perf_counter()-t0)/60
     print("prec", prec, f"{B/dt:.0f} env-steps/s", "nan", int(sim.get_flags().sum()), "Nu", float(sim.get_nusselt().mean()))
     sim.close()
 PY

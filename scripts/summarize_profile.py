@@ -164,6 +164,6 @@ streaming("trace3d", "pmc_fetch3d", "pmc_write3d", "3d", {"dim": 3, "batch": 32,
 streaming("trace3d_g1", "pmc_fetch3d_g1", "pmc_write3d_g1", "3d_g1", {"dim": 3, "batch": 32, "ra": 1e4, "precision": "f64", "groups": 1}, 7, "bench_trace3d_g1.log",
           "configs[4] float64, RBC_3D_GROUPS=1: one chain on the handle's stream (clean per-kernel counters)")
 streaming("trace3d_f32", "pmc_fetch3d_f32", "pmc_write3d_f32", "3d_f32", {"dim": 3, "batch": 32, "ra": 1e4, "precision": "f32"}, 7, "bench_trace3d_f32.log",
-          "configs[4] float32 (rbc3f kernels, deferred w correction)")
+          "configs[4] float32 (rbc3f kernels)")
 streaming("trace_s2d", "pmc_fetch_s2d", "pmc_write_s2d", "stream2d_128x64", {"dim": 2, "batch": 1024, "nx": 128, "nz": 64, "precision": "f64"}, 4, None,
           "streaming 2D, 128x64 float64, B = 1024, 1 warm-up + 3 env-steps (scripts/stream2d_timing.py 1024 3 128 64)")

@@ -204,7 +204,7 @@ def test_float32_3d_within_stated_tolerances_of_the_float64_oracle(native, o3):
     out float32 observations anyway) at BASELINE.json configs[4]'s shape, from a DEVELOPED convecting state, one env-step of 13
     substeps.  Stated tolerances against the float64 oracle on the identical initial fields (float32-rounded on upload):
     tendencies 2e-5 of their maximum, b 1e-6 rel-L2, u, v, w 1e-4, Nusselt number 1e-5; divergence at float32 round-off.  The
-    deferred vertical correction (the float32 default) and the separate pass agree to float32 round-off."""
+    deferred vertical correction (RBC_DEFER_W=1) and the separate pass agree to float32 round-off."""
     shape, ra, B = (32, 48, 48), 1e4, 2
     gen = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, random_kick=0.1)
     gen.reset(np.array([11, 12], dtype=np.uint64))
@@ -551,7 +551,7 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
 
 
 def test_deferred_vertical_correction_agrees_with_the_separate_pass(native, monkeypatch):
-    """RBC_DEFER_W=1 (an experiment kept off by default: parity-green but 18 % slower, rbc3d_host.hpp): w -= dts dphi/dz of a
+    """RBC_DEFER_W=1 (an experiment kept off by default: parity-green but slower in both precisions, rbc3d_host_body.hpp): w -= dts dphi/dz of a
     stage's projection is applied by the NEXT stage's tile kernels as they load w (planes and own-column windows) instead of
     the k3_correct_w pass.  Same expression on the same operands: round-off agreement over two env-steps incl. a clipped last
     substep, on the constant-grid (48 x 48), the generic (40 x 48 -> 8 x 8 tiles) and the registry-default instantiations."""
