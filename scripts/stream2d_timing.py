@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the streaming 2D path (2D grids without an LDS-resident kernel) and, on the default grid, against the resident kernel.
-usage: python scripts/stream2d_timing.py [B] [steps] [nx nz]"""
+usage: python scripts/stream2d_timing.py [B] [steps] [nx nz [precision]]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rbc-gym_amd"))
@@ -28,7 +28,8 @@ def run(label, **kw):
 
 if len(sys.argv) > 4:            # one grid only (profiling): B steps nx nz
     nx, nz = int(sys.argv[3]), int(sys.argv[4])
-    run(f"{nx}x{nz} streaming", nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8)
+    prec = sys.argv[5] if len(sys.argv) > 5 else "f64"
+    run(f"{nx}x{nz} streaming {prec}", nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8, precision=_native.PRECISIONS[prec])
     sys.exit(0)
 run("96x64 resident")
 os.environ["RBC_FORCE_STREAM2D"] = "1"
