@@ -419,7 +419,11 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
     // (tall chunks while the launch keeps a few hundred workgroups; a small batch takes 4 levels: its step is a chain of short kernels)
     if (h->stream2d && !h->no_tile && g.nx <= 256 && g.nz % 4 == 0) {
         auto enough = [&](int kt) { return g.nz % kt == 0 && 2 * (size_t)B * (g.nz / kt) >= 256; };
-        shape = enough(16) ? 5 : (enough(8) ? 6 : 7);
+        shape = (g.nz >= 64 && enough(32)) ? 8 : (enough(16) ? 5 : (enough(8) ? 6 : 7));     // 32 levels: +1.8 % at 128 x 64 (64: -6 %)
+        if (const char *e = std::getenv("RBC_FLAT_KT")) {                                      // A/B knob: 4, 8, 16, 32, 64
+            const int kt = std::atoi(e);
+            if (kt > 0 && g.nz % kt == 0) shape = kt == 64 ? 9 : (kt == 32 ? 8 : (kt == 16 ? 5 : (kt == 8 ? 6 : (kt == 4 ? 7 : shape))));
+        }
     }
     // RBC_DEFER_W=1: the vertical half of a stage's projection deferred into the next stage's tile kernels (tile_correct_w) instead
     // of the separate k3_correct_w pass: one launch and 1.2 MB per env and stage less.  Parity-green in both precisions
@@ -481,6 +485,8 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             else if (shape == 5) RBC_FLAT_LAUNCH(16)
             else if (shape == 6) RBC_FLAT_LAUNCH(8)
             else if (shape == 7) RBC_FLAT_LAUNCH(4)
+            else if (shape == 8) RBC_FLAT_LAUNCH(32)
+            else if (shape == 9) RBC_FLAT_LAUNCH(64)
 #undef RBC_FLAT_LAUNCH
             else if (g.nz % K3::KC3 == 0 && !h->no_march) {      // z-marching kernels (register reuse along z)
                 const dim3 gm_(grid_for((size_t)B * g.nx * g.ny * (g.nz / K3::KC3), 128));
