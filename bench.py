@@ -534,11 +534,11 @@ def main():
                 extra["gym_api_env_steps_per_s"] = {
                     "no_info_state": gym_api_rate(ctx, B, 5, False), "pinned_info_state": gym_api_rate(ctx, B, 5, "pinned"),
                     "note": "B x VectorEnv.step() per wall second, host actions in, host obs/reward/info out; 5 steps after 1 warm-up"}
-                d3 = run_3d(ctx, 32, 5, 2, 1e4)
+                d3 = run_3d(ctx, 32, 10, 3, 1e4)
                 extra["config4_3d"] = {k: d3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                           "nan_envs", "mean_nusselt")}
                 if _native.has_precision("f32"):           # the float32 instantiation of the same 3D kernels (153 MB algorithmic per env-step)
-                    d3f = run_3d(ctx, 32, 5, 2, 1e4, "f32")
+                    d3f = run_3d(ctx, 32, 10, 3, 1e4, "f32")
                     extra["config4_3d_fp32"] = {k: d3f[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
                                                                     "roofline", "nan_envs", "mean_nusselt")}
                 if not f32 and _native.has_precision("f32"):
