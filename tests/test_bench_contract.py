@@ -104,3 +104,18 @@ def test_extra_keys_are_measured_in_the_same_run():
     assert sc["nan_envs"] == 0 and abs(sc["kinetic_energy"] / sc["reference_kinetic_energy"] - 1) < 1e-4 and sc["max_rel_ke_drift_per_env_step"] < 1e-4
     s2 = x["streaming_2d_128x64"]                           # a grid without an LDS-resident kernel: the streaming 2D path
     assert s2["nan_envs"] == 0 and s2["value"] > 0 and 0.0 < s2["mean_nusselt_state"] < 6.0
+
+
+def test_cpu_baseline_reports_the_compute_it_actually_got():
+    """The CPU-baseline leg on THIS machine (no GPU needed): worker count bounded by affinity, cgroup quota and physical cores;
+    the N-worker total within a factor of two of N single workers; the per-core rate is what the bench line's reader needs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    c = bench.cpu_baseline(dim=2, envs=8, budget_s=3.0)
+    assert c["kind"] == "port" and c["unit"] == "env-steps/s" and 1 <= c["cores"] <= c["affinity"] and c["cores"] <= c["physical_cores"]
+    if c["cgroup_cpu_quota"] is not None:
+        assert c["cores"] <= int(c["cgroup_cpu_quota"] + 0.5) or c["cores"] == 1
+    assert c["single_worker"] > 0 and abs(c["per_core"] * c["cores"] - c["value"]) < 1e-9 * c["value"]
+    assert 0.5 * c["cores"] < c["cores_effective"] < 2.0 * c["cores"], c
+    q = bench._cpu_quota()
+    assert q is None or q > 0
