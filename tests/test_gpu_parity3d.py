@@ -529,6 +529,7 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
     act = np.random.default_rng(8).uniform(-1, 1, (3, B, 8, 8)).astype(np.float32)
     outs = []
     for env in (dict(RBC_3D_GROUPS="1", RBC_TILE_SHAPE="16x16"), dict(RBC_TILE_SHAPE="16x16"), dict(RBC_3D_GROUPS="3", RBC_USE_GRAPH="0", RBC_TILE_SHAPE="16x16"),
+                dict(RBC_3D_SLICES="2", RBC_3D_GROUPS="2", RBC_TILE_SHAPE="16x16"),       # two sequential time slices of 8 envs, two chains each
                 dict(), dict(RBC_3D_GROUPS="1"), dict(RBC_3D_GROUPS="2", RBC_TILE_SHAPE="16x8")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -540,11 +541,11 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
         sim.close()
         for k in env:
             monkeypatch.delenv(k)
-    for f, nu, st, fl in outs[1:3]:
+    for f, nu, st, fl in outs[1:4]:
         for x, y in zip(f, outs[0][0]):
             assert np.array_equal(x, y)
         assert np.array_equal(nu, outs[0][1]) and np.array_equal(st, outs[0][2]) and np.array_equal(fl, outs[0][3])
-    for f, nu, st, fl in outs[3:]:
+    for f, nu, st, fl in outs[4:]:
         for x, y in zip(f, outs[0][0]):
             assert rel_l2(x, y) < 1e-12
     assert len({float(x) for x in outs[0][1]}) == B             # 16 different envs, not copies

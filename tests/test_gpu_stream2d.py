@@ -307,3 +307,30 @@ def test_float32_streaming_2d_within_stated_tolerances_of_the_float64_oracle(nat
         div = (np.roll(u[e], -1, axis=1) - u[e]) / dx + (w[e][1:] - w[e][:-1]) / dz
         assert np.abs(div).max() < 2e-5 * max(np.abs(u[e]).max() / dx, 1e-3)
     sim.close()
+
+
+def test_streaming_chunk_heights_and_chain_counts_change_nothing(native, monkeypatch):
+    """The FLAT tile kernel marches 4 / 8 / 16 / 32 / 64 levels per workgroup (RBC_FLAT_KT; default by grid and batch) and the batch
+    runs on 1-4 stream chains (RBC_3D_GROUPS; default 3 from B = 768 up): other instantiations and launch orders of the same
+    per-cell expressions -- round-off between chunk heights (the compiler's contraction may differ), bitwise between chain counts."""
+    B = 12
+    act = np.random.default_rng(2).uniform(-1, 1, (2, B, 12)).astype(np.float32)
+    outs = {}
+    for name, env in (("kt16_g1", dict(RBC_FLAT_KT="16", RBC_3D_GROUPS="1")), ("kt16_g3", dict(RBC_FLAT_KT="16", RBC_3D_GROUPS="3")),
+                      ("kt32", dict(RBC_FLAT_KT="32", RBC_3D_GROUPS="1")), ("kt64", dict(RBC_FLAT_KT="64", RBC_3D_GROUPS="1")),
+                      ("kt4", dict(RBC_FLAT_KT="4", RBC_3D_GROUPS="2"))):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = native.NativeSim(batch=B, nx=128, nz=64, obs_nx=64, obs_nz=8, dt_control=0.09, dt_solver=0.03, random_kick=0.05)
+        sim.reset(np.arange(B, dtype=np.uint64) + 3)
+        for n in range(2):
+            assert sim.step(act[n])
+        outs[name] = (sim.get_fields(), sim.get_nusselt())
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for x, y in zip(outs["kt16_g1"][0], outs["kt16_g3"][0]):
+        assert np.array_equal(x, y)
+    for name in ("kt32", "kt64", "kt4"):
+        for x, y in zip(outs["kt16_g1"][0], outs[name][0]):
+            assert rel_l2(y, x) < 1e-12, name
