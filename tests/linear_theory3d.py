@@ -124,6 +124,33 @@ class LinearRBC3D:
         return out / nmodes / self.kappa
 
 
+def growth_rate(ra, kt2_window=(1.0, 4.5), **kw):
+    """largest growth rate over the horizontal modes with modified wavenumber^2 inside `kt2_window` (the null eigenvalues the
+    projector adds are left out) and the mode that has it"""
+    lin = LinearRBC3D(ra, **kw)
+    vals, _ = lin.mode_set()
+    best, at = -np.inf, None
+    for kt2 in vals[(vals >= kt2_window[0]) & (vals <= kt2_window[1])]:
+        ev = np.linalg.eigvals(lin.mode_operator(kt2)[0]).real
+        ev = ev[np.abs(ev) > 1e-9]
+        if ev.max() > best:
+            best, at = float(ev.max()), float(kt2)
+    return best, at
+
+
+def critical_rayleigh(lo=190.0, hi=230.0, iters=10, **kw):
+    """onset of convection of the DISCRETE operator on the protocol's grid, in the reference's units (Ra_classical = 8 Ra: SURVEY P5)"""
+    at = None
+    for _ in range(iters):
+        mid = 0.5 * (lo + hi)
+        s, k = growth_rate(mid, **kw)
+        if s > 0:
+            hi, at = mid, k
+        else:
+            lo = mid
+    return 0.5 * (lo + hi), at
+
+
 if __name__ == "__main__":
     import os
     import sys

@@ -112,3 +112,15 @@ def test_oracle_itself_follows_the_theory_at_the_flowstats_protocol(data):
     i = int(np.argmin(np.abs(ref["ra"] - 16000.0)))
     r = np.diff(np.log(ref["nusselt"][i, :8] - 1.0))[2:7]
     assert np.all(r / inc < 0.99) and np.mean(r / inc) < 0.982
+
+
+def test_linear_theory_reproduces_the_classical_onset():
+    """Independent check of the theory tool, hence of the restated linear operator (C-grid Laplacians, buoyancy averaged to the w
+    faces, no-slip / fixed-temperature ghost cells, exact projection): the discrete operator on the protocol's 32 x 64 x 64 grid
+    goes unstable at Ra = 212.4 in the reference's units, i.e. 8 x 212.4 = 1699 in the classical ones (nu, kappa assume
+    H = 1 but H = 2), at |k| = 1.576 -- Rayleigh-Benard convection between rigid plates: 1707.76 at k H = 3.117 (k = 1.5585);
+    0.5 % below, the second-order error of 32 cells across the layer."""
+    from linear_theory3d import critical_rayleigh
+    rc, kt2 = critical_rayleigh()
+    assert abs(8.0 * rc / 1707.76 - 1.0) < 0.008, rc
+    assert abs(np.sqrt(kt2) - 1.5585) < 0.06, kt2
