@@ -124,6 +124,41 @@ class LinearRBC3D:
         return out / nmodes / self.kappa
 
 
+def energy_series_2d(ra, steps, dt=0.03, nsub=50, shape=(64, 96), domain=(2.0, 2 * pi), kick=0.01, pr=0.7):
+    """E[KE] = E[(<u^2> + <w^2>) / 2] of a 2D env (rbc_sim2D.jl:163-171 initial condition, `set!`'s projection, zero action) after each of
+    `steps` env-steps of nsub RK3 substeps -- the same covariance propagation as LinearRBC3D.nusselt_series with ny = 1; the
+    horizontal-mean mode of u (no pressure, pure diffusion between the no-slip walls) is carried separately.  What the linear
+    phase of a from-rest run of the 2D kernel MUST show: pins its clock and linear operator with no reference data."""
+    nz, nx = shape
+    lin = LinearRBC3D(ra, pr=pr, shape=(nz, 1, nx), domain=(domain[0], 1.0, domain[1]), kick=kick)
+    vals, counts = lin.mode_set()
+    s2 = kick ** 2
+    nf = nz - 1
+    var_b = np.full(nz, s2)
+    c = (lin.beta * 0.5 * lin.dz) / kick
+    var_b[0] = var_b[-1] = s2 * _clamped_normal_variance(c)
+    out = np.zeros(steps)
+    for kt2, mult in zip(vals, counts):
+        M, P, (iu, iw, ib) = lin.mode_operator(kt2)
+        n = M.shape[0]
+        z = dt * M
+        Rn = np.linalg.matrix_power(np.eye(n) + z + z @ z / 2.0 + z @ z @ z / 6.0, nsub)
+        C = np.zeros((n, n))
+        C[iu, iu] = s2 * np.eye(nz); C[iw, iw] = s2 * np.eye(nf); C[ib, ib] = np.diag(var_b)
+        C = P @ C @ P.T
+        for s in range(steps):
+            C = Rn @ C @ Rn.T
+            out[s] += mult * 0.5 * (np.trace(C[iu, iu]) + np.trace(C[iw, iw])) / nz
+    # horizontal mean of u: du/dt = nu d2c u
+    z = dt * lin.nu * lin.d2c
+    Rn = np.linalg.matrix_power(np.eye(nz) + z + z @ z / 2.0 + z @ z @ z / 6.0, nsub)
+    C = s2 * np.eye(nz)
+    for s in range(steps):
+        C = Rn @ C @ Rn.T
+        out[s] += 0.5 * np.trace(C) / nz
+    return out / nx
+
+
 def growth_rate(ra, kt2_window=(1.0, 4.5), **kw):
     """largest growth rate over the horizontal modes with modified wavenumber^2 inside `kt2_window` (the null eigenvalues the
     projector adds are left out) and the mode that has it"""

@@ -442,3 +442,34 @@ def test_float32_packed_and_scalar_kernels_agree_and_pairs_are_independent(nativ
     for x, y, z in zip(before, after, (b0, u0, w0)):
         assert np.array_equal(x[[0, 2, 3]], y[[0, 2, 3]]) and rel_l2(y[1], z[1]) < 1e-5 and not np.array_equal(x[1], y[1])
     sim.close()
+
+
+def test_from_rest_linear_growth_follows_the_theory_of_the_discretisation(native):
+    """The 2D kernel's CLOCK and linear operator, with no reference data and no oracle: while the perturbation is small a from-rest
+    run (rbc_sim2D.jl:163-171 initial condition, zero action, 50 RK3 substeps of 0.03 per env-step) is a linear stochastic problem
+    whose ensemble-mean kinetic energy follows from propagating the white-noise covariance through 1 + z + z^2/2 + z^3/6 of dt P L
+    (tests/linear_theory3d.py::energy_series_2d; the same tool reproduces the classical onset of convection).  1024 members at
+    Ra = 1e4: the mean KE after each of the first seven env-steps within 3 standard errors + 1 % of the prediction, its growth per
+    env-step within 1 % once the fastest modes dominate.  The reference's data hold no time axis for the 2D env; this is the pin of
+    the headline kernel's time scale."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from linear_theory3d import energy_series_2d
+    B, steps = 1024, 7
+    th = energy_series_2d(1e4, steps)
+    sim = native.NativeSim(batch=B, ra=1e4)
+    sim.reset(np.arange(B, dtype=np.uint64) + 9000)
+    zero = np.zeros((B, 12), np.float32)
+    ke = []
+    for n in range(steps):
+        assert sim.step(zero)
+        b, u, w = sim.get_fields()
+        ke.append(0.5 * ((u ** 2).mean(axis=(1, 2)) + (w[:, :-1] ** 2).mean(axis=(1, 2))))
+    sim.close()
+    ke = np.array(ke)                                                  # [step, member]
+    m, se = ke.mean(1), ke.std(1, ddof=1) / np.sqrt(B)
+    assert np.all(np.abs(m / th - 1.0) < 3.0 * se / m + 0.01), (m / th, se / m)
+    inc, inc_th = np.diff(np.log(m)), np.diff(np.log(th))
+    assert np.all(np.abs(inc[2:] / inc_th[2:] - 1.0) < 0.01), inc / inc_th
+    assert th[-1] < 1e-3                                               # still 1 % of the saturated 0.098: linear
+    print(f"2D linear growth: KE/theory {m / th}, increments/theory {inc / inc_th}")
