@@ -444,20 +444,22 @@ def test_float32_packed_and_scalar_kernels_agree_and_pairs_are_independent(nativ
     sim.close()
 
 
-def test_from_rest_linear_growth_follows_the_theory_of_the_discretisation(native):
+@pytest.mark.parametrize("grid,precision", [((64, 96), 0), ((64, 128), 0), ((64, 96), 1)], ids=["96x64-resident", "128x64-streaming", "96x64-float32"])
+def test_from_rest_linear_growth_follows_the_theory_of_the_discretisation(native, grid, precision):
     """The 2D kernel's CLOCK and linear operator, with no reference data and no oracle: while the perturbation is small a from-rest
     run (rbc_sim2D.jl:163-171 initial condition, zero action, 50 RK3 substeps of 0.03 per env-step) is a linear stochastic problem
     whose ensemble-mean kinetic energy follows from propagating the white-noise covariance through 1 + z + z^2/2 + z^3/6 of dt P L
     (tests/linear_theory3d.py::energy_series_2d; the same tool reproduces the classical onset of convection).  1024 members at
     Ra = 1e4: the mean KE after each of the first seven env-steps within 3 standard errors + 1 % of the prediction, its growth per
-    env-step within 1 % once the fastest modes dominate.  The reference's data hold no time axis for the 2D env; this is the pin of
+    env-step within 1 % once the fastest modes dominate -- on the LDS-resident kernel, on the streaming path (128 x 64) and in float32.  The reference's data hold no time axis for the 2D env; this is the pin of
     the headline kernel's time scale."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from linear_theory3d import energy_series_2d
     B, steps = 1024, 7
-    th = energy_series_2d(1e4, steps)
-    sim = native.NativeSim(batch=B, ra=1e4)
+    nz, nx = grid
+    th = energy_series_2d(1e4, steps, shape=grid)
+    sim = native.NativeSim(batch=B, ra=1e4, nx=nx, nz=nz, obs_nx=nx // 2, obs_nz=8, precision=precision)
     sim.reset(np.arange(B, dtype=np.uint64) + 9000)
     zero = np.zeros((B, 12), np.float32)
     ke = []
