@@ -6,7 +6,7 @@
     python examples/demo.py vector [envs] [steps]   gym.make_vec -> ONE device-batched env (6 or 6000 envs alike)
     python examples/demo.py wrapped [steps]         observation / reward normalisation + reward shaping wrappers
     python examples/demo.py checkpoint [file] [steps]   episodes from converged states (generated on the GPU if absent)
-    python examples/demo.py three-d [time]          the 3D env
+    python examples/demo.py three-d [time] [f32]    the 3D env (f32: the float32 instantiation of the 3D kernels, 1.5x at configs[4])
     python examples/demo.py timing [iterations]     construction / reset / step latency of one env
 """
 import os
@@ -98,7 +98,9 @@ def checkpoint(args):
 
 
 def three_d(args):
-    env = gym.make(ENV3D, rayleigh_number=2500, heater_duration=0.25, episode_length=_int(args, 0, 50))
+    precision = "f32" if "f32" in args else "f64"
+    args = [a for a in args if a != "f32"]
+    env = gym.make(ENV3D, rayleigh_number=2500, heater_duration=0.25, episode_length=_int(args, 0, 50), precision=precision)
     obs, _ = rollout(env, 10**9, zero_action, keys=("nusselt",))
     print("observation", obs.shape)
     env.close()
