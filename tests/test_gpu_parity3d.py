@@ -284,6 +284,28 @@ def test_float32_3d_flowstats_statistics(native):
     sim.close()
 
 
+def test_float32_3d_linear_growth_follows_the_theory(native, golden_dir):
+    """The float32 3D path against the discretisation's linear theory (tests/linear_theory3d.py, no reference data, no oracle): 32
+    members at Ra = 16000 on the flow-statistics protocol, increments of log(Nu-1) per env-step within 1 % of the theory's for 50
+    solver steps (float64 ensembles: 0.05-0.3 %)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(golden_dir))
+    from linear_theory3d import LinearRBC3D
+    B = 32
+    sim = native.NativeSim3D(batch=B, shape=(32, 64, 64), ra=16000.0, dt_control=0.25, dt_solver=0.005, precision="f32")
+    sim.reset(np.arange(B, dtype=np.uint64) + 600)
+    zero = np.zeros((B, 8, 8), np.float32)
+    nus = []
+    for n in range(8):
+        assert sim.step(zero)
+        nus.append(sim.get_nusselt().copy())
+    sim.close()
+    la = np.log(np.array(nus) - 1.0).mean(1)
+    th = np.log(LinearRBC3D(16000.0).nusselt_series(8, 0.02, 50))
+    assert np.all(np.abs(np.diff(la)[2:7] / np.diff(th)[2:7] - 1.0) < 0.01), np.diff(la) / np.diff(th)
+    assert abs(la[0] - th[0]) < 0.03
+
+
 def test_fast_fft_sizes(native, o3):
     """48 = 6x8 and 64 = 8x8 take the register-blocked slab FFT (dft6 / dft8 x dft8); the other tests
     run 32 = 4x8 and the generic 24 = 4x6 path."""
