@@ -507,3 +507,8 @@ class NativeSim3D:
     def debug_substeps(self, actions, nsub, dt):
         a = self._actions(actions)
         self._check(self.lib.rbc_debug_substeps(self.h, _ptr(a, _fp), int(nsub), float(dt)))
+
+    def dev_ptrs(self):
+        L = self.lib
+        return dict(state=L.rbc_dev_state(self.h), nusselt=L.rbc_dev_nusselt(self.h), flags=L.rbc_dev_flags(self.h),
+                    fields=L.rbc_dev_fields(self.h))

@@ -243,6 +243,21 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
     def _observations(self):
         return self.sim.get_state()
 
+    def device_views(self):
+        """zero-copy views of the library's output buffers (SURVEY 8(f) row 2 for the 3D env, whose observation IS the float32
+        state: rbc3D.py:229-232): "obs" (B, 4, Nz, Ny, Nx) float32, "nusselt" (B,) float64, "flags" (B,) int32; with devices=[...] a
+        LIST with one dict per shard, each on its own GPU and covering that shard's contiguous env range (`self.sim.ranges`).
+        Same stream rules as `step_device`."""
+        nz, ny, nx = self.state_shape
+
+        def views(p, B):
+            return {"obs": DeviceArray(p["state"], (B, 4, nz, ny, nx), "<f4", self), "nusselt": DeviceArray(p["nusselt"], (B,), "<f8", self),
+                    "flags": DeviceArray(p["flags"], (B,), "<i4", self)}
+        if self.devices is None:
+            return views(self.sim.dev_ptrs(), self.num_envs)
+        return [dict(views(p, count), device=dev, env_range=(start, start + count))
+                for p, dev, (start, count) in zip(self.sim.dev_ptrs(), self.devices, self.sim.ranges)]
+
     def _stacked_info(self):
         t, step = self.sim.get_info()
         nu = self.sim.get_nusselt()

@@ -194,6 +194,29 @@ def test_device_views_are_zero_copy_torch_tensors(gym):
     venv.close()
 
 
+def test_3d_device_views_are_zero_copy_torch_tensors(gym):
+    """The device-resident rollout path of the 3D vector env (the reference trains its PPO policy on this env's full-state
+    observation, experiments/run_sarl.py:152-153): torch views over the library's float32 state / Nusselt / flag buffers, actions
+    from a device tensor, no host hop."""
+    torch = pytest.importorskip("torch")
+    ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
+    for prec in ("f64", "f32"):
+        venv = gym.make_vec(ID3, num_envs=4, state_shape=(16, 32, 32), heater_duration=0.0625, precision=prec)
+        obs, _ = venv.reset(seed=2)
+        v = venv.device_views()
+        t_obs = torch.as_tensor(v["obs"], device="cuda")
+        assert t_obs.shape == (4, 4, 16, 32, 32) and t_obs.is_cuda and t_obs.dtype == torch.float32
+        assert np.array_equal(t_obs.cpu().numpy(), obs)
+        acts = torch.rand((4, 8, 8), device="cuda") * 2 - 1
+        torch.cuda.synchronize()
+        venv.step_device(acts.data_ptr())
+        venv.sim.synchronize()
+        assert np.array_equal(torch.as_tensor(v["obs"], device="cuda").cpu().numpy(), venv.sim.get_state())
+        assert np.array_equal(torch.as_tensor(v["nusselt"], device="cuda").cpu().numpy(), venv.sim.get_nusselt())
+        assert not np.array_equal(venv.sim.get_state(), obs) and int(torch.as_tensor(v["flags"], device="cuda").sum()) == 0
+        venv.close()
+
+
 @pytest.mark.parametrize("dt_control", [1.5, 0.3], ids=["full-interval-50-substeps", "10-substeps"])
 def test_full_batch_properties(dt_control):
     """BASELINE.json configs[1] size (B=1024) at the control interval the bench times (heater_duration 1.5 = 50 RK3
