@@ -345,6 +345,24 @@ def steady_ckpt_extra(ctx, B, K):
     return out
 
 
+def gym_api_rate_3d(ctx, B, steps, obs_buffers, precision="f64"):
+    """configs[4] through the gym API: B x VectorEnv.step() per wall second, host actions in, host observations (the float32
+    states: 38 MB per step at B = 32) / rewards / infos out -- what the reference's SubprocVecEnv workers deliver to PPO."""
+    np = ctx["np"]
+    from rbc_gym.vector import RayleighBenardConvection3DVectorEnv
+    venv = RayleighBenardConvection3DVectorEnv(num_envs=B, state_shape=(32, 48, 48), rayleigh_number=1e4, device=ctx["local_rank"],
+                                               episode_length=10**9, obs_buffers=obs_buffers, precision=precision)
+    venv.reset(seed=1234)
+    acts = np.random.default_rng(5).uniform(-1, 1, (steps + 1, B, 8, 8)).astype(np.float32)
+    venv.step(acts[0])
+    t0 = time.perf_counter()
+    for n in range(steps):
+        venv.step(acts[n + 1])
+    dt = time.perf_counter() - t0
+    venv.close()
+    return B * steps / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -537,6 +555,10 @@ def main():
                 d3 = run_3d(ctx, 32, 10, 3, 1e4)
                 extra["config4_3d"] = {k: d3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                           "nan_envs", "mean_nusselt")}
+                extra["gym_api_3d_env_steps_per_s"] = {
+                    "fresh_arrays": gym_api_rate_3d(ctx, 32, 8, None), "pinned_buffers": gym_api_rate_3d(ctx, 32, 8, "pinned"),
+                    "pinned_buffers_fp32": gym_api_rate_3d(ctx, 32, 8, "pinned", "f32") if _native.has_precision("f32") else None,
+                    "note": "configs[4], B x VectorEnv.step() per wall second with the 38 MB of float32 observations crossing PCIe every step; 8 steps after 1 warm-up"}
                 if _native.has_precision("f32"):           # the float32 instantiation of the same 3D kernels (153 MB algorithmic per env-step)
                     d3f = run_3d(ctx, 32, 10, 3, 1e4, "f32")
                     extra["config4_3d_fp32"] = {k: d3f[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",

@@ -456,8 +456,12 @@ class NativeSim3D:
     def step_dev(self, actions_dev_ptr):
         self._check(self.lib.rbc_step_dev(self.h, _vp(actions_dev_ptr)))
 
-    def get_state(self):
-        o = np.empty((self.B, 4, self.nz, self.ny, self.nx), np.float32)
+    def get_state(self, out=None):
+        """float32 (B, 4, nz, ny, nx); `out` may be a caller-owned array of that shape, e.g. from pinned_empty()"""
+        shape = (self.B, 4, self.nz, self.ny, self.nx)
+        o = np.empty(shape, np.float32) if out is None else out
+        if o.shape != shape or o.dtype != np.float32 or not o.flags.c_contiguous:
+            raise ValueError(f"get_state: out must be a C-contiguous float32 array of shape {shape}")
         self._check(self.lib.rbc_get_state(self.h, _ptr(o, _fp), 4))
         return o
 

@@ -116,7 +116,7 @@ class ShardedSim:
     def get_obs(self, *a):
         return self._cat(self._all(lambda r, sim: sim.get_obs(*a)))
 
-    def get_state(self, *a, out=None):
+    def get_state(self, *a, out=None):                       # (2D: nch positional; 3D: no positional argument)
         if out is None:
             return self._cat(self._all(lambda r, sim: sim.get_state(*a)))
         self._all(lambda r, sim: sim.get_state(*a, out=self._slice(r, out)))          # shard slices of a C-contiguous array are contiguous
