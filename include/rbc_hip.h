@@ -104,7 +104,10 @@ int  rbc_set_rayleigh(rbc_handle *h, const double *ra);
    in float32 in exactly that order on the float32-rounded sample, the python-float bounds rounded to float32 where
    numpy rounds them (bit-identical to the numpy wrapper), then
    clipped to [-maxval, maxval] if clip != 0.  nch <= 5 channels (b,u,w,pHY',pNHS); channels >= nch stay raw;
-   nch = 0 switches the transform off.  Takes effect from the next reset/step; rbc_get_state is never transformed. */
+   nch = 0 switches the transform off.  Takes effect from the next reset/step; rbc_get_state is never transformed.
+   dim=3: nch <= 4 channels (b,u,v,w).  The 3D observation IS the float32 state buffer (rbc3D.py:229-232), so there the
+   transform applies to what rbc_get_obs / rbc_get_state / rbc_dev_state hand out (rewritten at once for the current state);
+   Nusselt number, NaN flag and rbc_get_fields3 always come from the raw float64 state. */
 int  rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip);
 
 /* RBCRewardShaping.compute_cell_distances (wrappers/rbc_reward_shaping.py:85-140) on the device, for every env of a dim=2

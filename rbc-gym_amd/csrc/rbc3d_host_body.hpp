@@ -364,8 +364,11 @@ int output3d(rbc_handle *h, const rbc3_grp &q, int which, const uint8_t *mask)
         HIP3(hipGetLastError());
         return RBC_OK;
     }
+    K3::ObsNorm3 nrm{};
+    nrm.n = h->obs_norm > 4 ? 4 : h->obs_norm; nrm.clip = h->obs_clip; nrm.maxval = h->obs_maxval;
+    for (int c = 0; c < 4; ++c) { nrm.mn[c] = h->obs_min[c]; nrm.rng[c] = h->obs_rng[c]; }
     hipLaunchKernelGGL(K3::k3_output, dim3(q.B * K3::OUT_SPLIT), dim3(256), 0, q.st, g, st, h->d_ra + (size_t)q.e0 * 2, h->d_state + (size_t)q.e0 * 4 * g.nc,
-                       h->d_nu + q.e0, h->d_flags + q.e0, mk, s->out_part + (size_t)q.e0 * 2 * K3::OUT_SPLIT, s->out_arrive + q.e0);
+                       h->d_nu + q.e0, h->d_flags + q.e0, mk, s->out_part + (size_t)q.e0 * 2 * K3::OUT_SPLIT, s->out_arrive + q.e0, nrm);
     HIP3(hipGetLastError());
     return RBC_OK;
 }
@@ -640,6 +643,14 @@ int get_field3d(rbc_handle *h, int f, double *out)
         HIP3(hipMemcpy2D(tmp.data(), count * sizeof(real), base, pitch, count * sizeof(real), h->B, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
     }
+    return RBC_OK;
+}
+
+// outputs of the current state again (after the observation normalisation changed)
+int refresh_outputs3d(rbc_handle *h)
+{
+    if (int rc = output3d(h, whole_batch(h), S3(h)->cur, nullptr)) return rc;
+    HIP3(hipStreamSynchronize(h->stream));
     return RBC_OK;
 }
 

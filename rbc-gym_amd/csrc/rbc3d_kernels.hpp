@@ -112,6 +112,22 @@ __global__ void __launch_bounds__(128) k2s_wall(Geo3 g, const float *actions, do
     wall[(size_t)env * g.nx + i] = Tb;
 }
 
+// RBCNormalizeObservation fused into the 3D output kernel's float32 state write (the 3D observation IS the state, rbc3D.py:229-232):
+// obs[c] <- maxval * (2 * (obs[c] - min[c]) / (max[c] - min[c]) - 1), optionally clipped -- the same float32 operations in the same
+// order as the numpy expression of rbc_normalize_observation.py:66-74 (no contraction), so results are bit-identical to the host wrapper.
+struct ObsNorm3 {
+    int n, clip;                // channels normalised (0: off), clip to [-maxval, maxval]
+    float mn[4], rng[4], maxval;
+};
+__device__ __forceinline__ float obs_value3(const ObsNorm3 &P, int c, float o)
+{
+    if (c < P.n) {
+        o = __fmul_rn(P.maxval, __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(o, P.mn[c])), P.rng[c]), 1.0f));
+        if (P.clip) o = fminf(fmaxf(o, -P.maxval), P.maxval);
+    }
+    return o;
+}
+
 struct Out2D {
     float *obs, *state32;       // [B][5][obs_nz][obs_nx], [B][5][nz][nx]
     double *nusselt;            // [B][2]

@@ -1678,7 +1678,7 @@ __global__ void k2s_clear_v(Geo3 g, real *st0, real *st1, const uint8_t *mask, i
 }
 
 __global__ void __launch_bounds__(256) k3_output(Geo3 g, const real *st, const f64 *nu_kappa, float *state32, f64 *nusselt, int *flags,
-                                                 const uint8_t *mask, f64 *part, unsigned int *arrive)
+                                                 const uint8_t *mask, f64 *part, unsigned int *arrive, ObsNorm3 norm)
 {
     __shared__ f64 red[256];
     __shared__ int bad, last;
@@ -1695,7 +1695,8 @@ __global__ void __launch_bounds__(256) k3_output(Geo3 g, const real *st, const f
     for (int c0 = sp * per + threadIdx.x; c0 < c_end; c0 += blockDim.x) {
         const int k = c0 / pln;
         const f64 b = sb[c0], u = sb[g.nc + c0], v = sb[2 * (size_t)g.nc + c0], w = sb[3 * (size_t)g.nc + c0];
-        o[c0] = (float)b; o[g.nc + c0] = (float)u; o[2 * (size_t)g.nc + c0] = (float)v; o[3 * (size_t)g.nc + c0] = (float)w;
+        o[c0] = obs_value3(norm, 0, (float)b); o[g.nc + c0] = obs_value3(norm, 1, (float)u);
+        o[2 * (size_t)g.nc + c0] = obs_value3(norm, 2, (float)v); o[3 * (size_t)g.nc + c0] = obs_value3(norm, 3, (float)w);
         const f64 zc = (k + real(0.5)) / g.nz, tc = (real(1.0) - zc) * g.delta_b + g.min_b;
         acc += (b - tc) * w;
         nan |= (isnan(b) || isnan(u) || isnan(v) || isnan(w)) ? 1 : 0;

@@ -573,8 +573,7 @@ static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t cha
 int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const double *max_vals, int nch, double maxval, int clip)
 {
     if (int rc = check_handle(h)) return rc;
-    if (is3d(h)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: the 3D observation is the raw state; normalise on the host");
-    if (nch < 0 || nch > 5) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: nch must be in [0, 5]");
+    if (nch < 0 || nch > (is3d(h) ? 4 : 5)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: nch must be in [0, 5] (dim=3: [0, 4], the channels b, u, v, w)");
     if (nch > 0 && (!min_vals || !max_vals)) return fail(RBC_ERR_INVALID, "rbc_set_obs_normalization: NULL bounds");
     for (int c = 0; c < nch; ++c) {
         // the numpy expression divides by the python float (max - min) cast to float32
@@ -584,6 +583,14 @@ int rbc_set_obs_normalization(rbc_handle *h, const double *min_vals, const doubl
     for (int c = 0; c < nch; ++c) { h->obs_min[c] = (float)min_vals[c]; h->obs_rng[c] = (float)(max_vals[c] - min_vals[c]); }
     h->obs_norm = nch; h->obs_clip = clip ? 1 : 0; h->obs_maxval = (float)maxval;
     if (h->s3) RBC_S3(h, drop_graphs3d, h);          // a captured env-step carries the old parameters as kernel arguments
+    if (is3d(h)) {                                   // the 3D observation IS the float32 state buffer: rewrite it for the current state
+        bool any = false;
+        for (uint8_t v : h->inited) any = any || v;
+        if (any) {
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            if (int rc = RBC_S3(h, refresh_outputs3d, h)) return rc;
+        }
+    }
     return RBC_OK;
 }
 

@@ -439,6 +439,17 @@ class NativeSim3D:
         r = np.ascontiguousarray(np.broadcast_to(np.asarray(ra, np.float64), (self.B,)))
         self._check(self.lib.rbc_set_rayleigh(self.h, _ptr(r, _dp)))
 
+    def set_obs_normalization(self, min_vals=None, max_vals=None, maxval=1.0, clip=False):
+        """RBCNormalizeObservation fused into the output kernel's float32 state write (channels b, u, v, w); None switches it off."""
+        if min_vals is None:
+            self._check(self.lib.rbc_set_obs_normalization(self.h, None, None, 0, 1.0, 0))
+            return
+        lo = np.ascontiguousarray(min_vals, np.float64)
+        hi = np.ascontiguousarray(max_vals, np.float64)
+        if lo.shape != hi.shape or lo.ndim != 1:
+            raise ValueError("set_obs_normalization: min_vals and max_vals must be 1-D and of equal length")
+        self._check(self.lib.rbc_set_obs_normalization(self.h, _ptr(lo, _dp), _ptr(hi, _dp), int(lo.size), float(maxval), int(bool(clip))))
+
     def _actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)
         if a.shape != (self.B, self.heaters, self.heaters):

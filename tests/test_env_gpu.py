@@ -194,6 +194,32 @@ def test_device_views_are_zero_copy_torch_tensors(gym):
     venv.close()
 
 
+def test_3d_observation_normalisation_runs_in_the_output_kernel(gym):
+    """VectorRBCNormalizeObservation on the 3D vector env (u_limit=None: the reference's saturating fit of max|w| over Ra,
+    rbc_normalize_observation.py:44-46,76-80): the affine map is applied by the output kernel as it writes the float32 state
+    (`rbc_set_obs_normalization`, dim=3) instead of numpy passes over 38 MB per step -- bit-identical to the numpy wrapper on
+    the raw observations, also through device_views; rewards, Nusselt numbers and fields stay raw."""
+    from rbc_gym.wrappers import VectorRBCNormalizeObservation
+    from rbc_gym.wrappers.normalize import normalization_bounds, normalize_channels
+    ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
+    kw = dict(num_envs=3, state_shape=(16, 32, 32), heater_duration=0.0625, rayleigh_number=5000)
+    raw, fused = gym.make_vec(ID3, **kw), VectorRBCNormalizeObservation(gym.make_vec(ID3, **kw), heater_limit=0.9, u_limit=None, clip=True)
+    assert fused.fused
+    lo, hi = normalization_bounds(raw.unwrapped, 0.9, None)
+    o_raw, _ = raw.reset(seed=9); o_f, _ = fused.reset(seed=9)
+    acts = np.random.default_rng(4).uniform(-1, 1, (2, 3, 8, 8)).astype(np.float32)
+    for n in range(2):
+        expect = np.clip(normalize_channels(o_raw.copy(), lo, hi, 1, channel_axis=1), -1, 1)
+        assert np.array_equal(o_f, expect)
+        xr, xf = raw.step(acts[n]), fused.step(acts[n])
+        o_raw, o_f = xr[0], xf[0]
+        assert np.array_equal(xr[1], xf[1]) and np.array_equal(xr[4]["nusselt"], xf[4]["nusselt"])
+    for x, y in zip(raw.sim.get_fields(), fused.unwrapped.sim.get_fields()):
+        assert np.array_equal(x, y)
+    assert fused.observation_space.shape == (3, 4, 16, 32, 32) and np.abs(o_f).max() <= 1.0
+    raw.close(); fused.close()
+
+
 def test_3d_vector_env_with_pinned_observation_buffers(gym):
     """`obs_buffers="pinned"`: the 3D vector env's observations (the float32 states, 38 MB per step at configs[4]) land in three
     rotating page-locked buffers instead of fresh pageable arrays (4.4k instead of 3.0k env-steps/s through the gym API at
