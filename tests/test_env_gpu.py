@@ -220,6 +220,63 @@ def test_3d_observation_normalisation_runs_in_the_output_kernel(gym):
     raw.close(); fused.close()
 
 
+def test_sb3_vec_env_adaptor(gym, monkeypatch):
+    """rbc_gym.sb3.make_sb3_vec_env: the batched env behind stable-baselines3's VecEnv conventions (the reference trains with
+    SubprocVecEnv, experiments/run_sarl.py:152-153): reset() -> obs only, step_async/step_wait -> (obs, rewards, dones, LIST of
+    infos), SAME-STEP autoreset with infos[i]["terminal_observation"] and "TimeLimit.truncated".  stable-baselines3 is not
+    installed here: a stand-in for its VecEnv base class (constructor and seed bookkeeping as in SB3 2.x) is injected."""
+    import sys
+    import types
+
+    class VecEnv:                                                   # stand-in: stable_baselines3.common.vec_env.base_vec_env.VecEnv
+        def __init__(self, num_envs, observation_space, action_space):
+            self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+            self.reset_infos = [{} for _ in range(num_envs)]
+            self._seeds = [None for _ in range(num_envs)]
+
+        def seed(self, seed=None):
+            self._seeds = [seed + i for i in range(self.num_envs)]
+            return self._seeds
+
+        def _reset_seeds(self):
+            self._seeds = [None for _ in range(self.num_envs)]
+
+        def step(self, actions):
+            self.step_async(actions)
+            return self.step_wait()
+    mods = {}
+    for name in ("stable_baselines3", "stable_baselines3.common", "stable_baselines3.common.vec_env", "stable_baselines3.common.vec_env.base_vec_env"):
+        mods[name] = types.ModuleType(name)
+        monkeypatch.setitem(sys.modules, name, mods[name])
+    mods["stable_baselines3.common.vec_env.base_vec_env"].VecEnv = VecEnv
+    from rbc_gym.sb3 import make_sb3_vec_env
+    ID3 = "rbc_gym/RayleighBenardConvection3D-v0"
+    kw = dict(state_shape=(16, 32, 32), heater_duration=0.0625, episode_length=0.5, rayleigh_number=5000)
+    ve = make_sb3_vec_env(ID3, n_envs=3, normalize=dict(heater_limit=0.9, u_limit=None), **kw)
+    assert isinstance(ve, VecEnv) and ve.num_envs == 3 and ve.action_space.shape == (8, 8) and ve.observation_space.shape == (4, 16, 32, 32)
+    ve.seed(11)
+    obs0 = ve.reset()
+    assert obs0.shape == (3, 4, 16, 32, 32) and len(ve.reset_infos) == 3 and ve.reset_infos[0]["step"] == 1
+    ref = gym.make_vec(ID3, num_envs=3, **kw)                       # the gymnasium-convention env, driven alike
+    from rbc_gym.wrappers import VectorRBCNormalizeObservation
+    ref = VectorRBCNormalizeObservation(ref, heater_limit=0.9, u_limit=None)
+    r0, _ = ref.reset(seed=11)
+    assert np.array_equal(obs0, r0)
+    acts = np.random.default_rng(6).uniform(-1, 1, (3, 3, 8, 8)).astype(np.float32)
+    o1, rew1, d1, inf1 = ve.step(acts[0])
+    g1 = ref.step(acts[0])
+    assert np.array_equal(o1, g1[0]) and np.allclose(rew1, g1[1]) and not d1.any() and isinstance(inf1, list) and inf1[2]["t"] == 0.25
+    o2, rew2, d2, inf2 = ve.step(acts[1])                           # t = 0.5 = episode_length: truncated, reset in the same call
+    g2 = ref.step(acts[1])
+    assert d2.all() and np.allclose(rew2, g2[1]) and all(i["TimeLimit.truncated"] for i in inf2)
+    assert np.array_equal(np.stack([i["terminal_observation"] for i in inf2]), g2[0])
+    assert np.array_equal(o2, obs0)                                 # same seeds: the new episodes start where the first ones did
+    o3, rew3, d3, inf3 = ve.step(acts[0])
+    assert np.array_equal(o3, o1) and inf3[0]["t"] == 0.25 and not d3.any()
+    assert ve.get_attr("ra") == [5000] * 3 and ve.env_is_wrapped(object) == [False] * 3
+    ve.close(); ref.close()
+
+
 def test_3d_vector_env_with_pinned_observation_buffers(gym):
     """`obs_buffers="pinned"`: the 3D vector env's observations (the float32 states, 38 MB per step at configs[4]) land in three
     rotating page-locked buffers instead of fresh pageable arrays (4.4k instead of 3.0k env-steps/s through the gym API at
