@@ -449,12 +449,18 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             else if (h->stream2d && n == nsub - 1 && ph >= 1)  // un-split tendencies: the two scans k2s_output needs to return pNHS
                 hipLaunchKernelGGL(K3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, q.st, g, cur,
                                    ph == 2 ? phy : s->phy2 + (size_t)q.e0 * g.nc, B);
+#undef RBC_TILE_NOPHI
+#if RBC_STAMPS            /* diagnostic build: the unused phi argument carries the stamp buffer (TSTAMP in rbc3d_kernels_body.hpp) */
+#define RBC_TILE_NOPHI reinterpret_cast<const real *>(h->d_stamps)
+#else
+#define RBC_TILE_NOPHI (const real *)nullptr
+#endif
 #define RBC_TILE_LAUNCH(TY, KT, THR, WAVES)                                                                                              \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * K3::NXP3 * sizeof(real);                                                        \
                 if (pending) hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, 0, 0, true>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, phi_g, dts_pending); \
-                else hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, (const real *)nullptr, 0.0); \
+                else hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_NOPHI, 0.0); \
             }
             // (48, 48) horizontal planes -- configs[4] --, the registry default (32, 32) and the flowstats experiment's (64, 64) have
             // instantiations with nx, ny as compile-time constants: the index arithmetic of the plane staging becomes multiplications
@@ -464,7 +470,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * K3::NXP3 * sizeof(real);                                                        \
                 if (pending) hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, NXC_, NYC_, true>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, phi_g, dts_pending); \
-                else hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, (const real *)nullptr, 0.0); \
+                else hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_NOPHI, 0.0); \
             }
             const bool c48 = (g.nx == 48 && g.ny == 48 && !no_nxc), c32 = (g.nx == 32 && g.ny == 32 && !no_nxc), c64 = (g.nx == 64 && g.ny == 64 && !no_nxc);
             if (shape == 1 && c48) RBC_TILE_LAUNCHC(16, 16, 768, TW3, 48, 48)
@@ -483,7 +489,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
 #define RBC_FLAT_LAUNCH(KT)                                                                                                              \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.nz / KT))), bt(g.nx);                                                         \
-                hipLaunchKernelGGL((K3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(real), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, (const real *)nullptr, 0.0); \
+                hipLaunchKernelGGL((K3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(real), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_NOPHI, 0.0); \
             }
             else if (shape == 5) RBC_FLAT_LAUNCH(16)
             else if (shape == 6) RBC_FLAT_LAUNCH(8)

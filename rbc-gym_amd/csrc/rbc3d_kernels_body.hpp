@@ -22,6 +22,9 @@ __device__ __forceinline__ real zfR(const real *p, int k, int N)
 { const int k1 = k + 1; return (k1 >= 4 && k1 <= N - 2) ? right5(p[1], p[2], p[3], p[4], p[5]) : ((k1 >= 3 && k1 <= N - 1) ? right3(p[2], p[3], p[4]) : p[3]); }
 __device__ __forceinline__ real zfS(const real *p, int k, int N)
 { const int k1 = k + 1; return (k1 >= 4 && k1 <= N - 2) ? sym4(p[1], p[2], p[3], p[4]) : real(0.5) * (p[2] + p[3]); }
+// the same from a four-level window p4[j] = psi[k-2+j] (all zfS reads)
+__device__ __forceinline__ real zfS4(const real *p4, int k, int N)
+{ const int k1 = k + 1; return (k1 >= 4 && k1 <= N - 2) ? sym4(p4[0], p4[1], p4[2], p4[3]) : real(0.5) * (p4[1] + p4[2]); }
 // face field -> centre k: p[j] = psi_face[k-2+j], j=0..5 (centre between p[2] | p[3])
 __device__ __forceinline__ real zcL(const real *p, int k, int N)
 { const int k1 = k + 1; return (k1 >= 3 && k1 <= N - 2) ? left5(p[0], p[1], p[2], p[3], p[4]) : ((k1 >= 2 && k1 <= N - 1) ? left3(p[1], p[2], p[3]) : p[2]); }
@@ -398,6 +401,33 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const real *cur, re
 // are never read again (zeta^1 = 0).
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
 
+// Diagnostic build only (-DRBC_STAMPS=1, never shipped; scripts/tile_stamps.py): wave 0 of every tile workgroup accumulates
+// s_memtime ticks per phase of its level loop and adds them to stamps[16 * body + id] (the `phi` argument carries the buffer).
+#undef TSTAMP
+#undef TSTAMP_INIT
+#undef TSTAMP_FLUSH
+#if RBC_STAMPS
+#define TSTAMP_INIT                                                                                 \
+    const bool ts_on = (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0);                \
+    unsigned int ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                              \
+    unsigned long long ts_last = ts_on ? __builtin_amdgcn_s_memtime() : 0ull
+#define TSTAMP(id)                                                                                  \
+    do {                                                                                            \
+        if (ts_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts_acc[id] += (unsigned int)(t_ - ts_last); ts_last = t_; } \
+    } while (0)
+#define TSTAMP_FLUSH(body, stamps)                                                                  \
+    do {                                                                                            \
+        if (ts_on && threadIdx.x == 0 && (stamps)) {                                                \
+            for (int q_ = 0; q_ < 8; ++q_) atomicAdd((unsigned long long *)(stamps) + 16 * (body) + q_, (unsigned long long)ts_acc[q_]); \
+            atomicAdd((unsigned long long *)(stamps) + 16 * (body) + 15, 1ull);                     \
+        }                                                                                           \
+    } while (0)
+#else
+#define TSTAMP_INIT
+#define TSTAMP(id)
+#define TSTAMP_FLUSH(body, stamps)
+#endif
+
 // FLAT (streaming-2D mode, ny = 1): a plane is ONE row of up to NXP values (no y halo), every y offset of a stencil read
 // aliases that row, and everything that involves v or a y-difference is compiled out (it is identically zero).
 // NXC > 0: nx (and, NYC, ny) known at compile time -- the index arithmetic of the plane staging (idx / nx, the row wrap) turns
@@ -538,8 +568,10 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
     tile_store(t, PW, pfw1);
     __syncthreads();
 
+    TSTAMP_INIT;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
         const bool more = (k + 1 < t.k0 + KT3);
+        TSTAMP(6);
 #pragma unroll
         for (int q = 0; q < 5; ++q) { winu[q] = winu[q + 1]; winv[q] = winv[q + 1]; }
         winu[5] = nu5; winv[5] = nv5;
@@ -556,6 +588,7 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
         const bool top = (k + 1 >= nz);
         const real wc = top ? real(0.0) : L(IW, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(0);
         // ---- u at (x-face i, j, k): `a` along x, `b` along y ----
         {
             const real f0 = winu[2];
@@ -587,6 +620,7 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             fbu = ft; dwbu = dwt; fdnu = f0;
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the two sections' live ranges apart
+        TSTAMP(1);
         // ---- v at (i, y-face j, k): the mirror image, `a` along y, `b` along x ----
         if constexpr (!FLAT) {
             const real f0 = winv[2];
@@ -614,6 +648,7 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             if (store_g) gm[o] = G;
             fbv = ft; dwbv = dwt; fdnv = f0;
         }
+        TSTAMP(2);
         if (more) {
             if constexpr (DEFW) {
                 if (k + 2 < nz) tile_correct_w(pfw, pfn, pfp, rdz, dts_prev);
@@ -621,12 +656,16 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
                 for (int q = 0; q < NPF; ++q) pfp[q] = pfn[q];
             }
             __syncthreads();                                      // every read of this level's planes is done
+            TSTAMP(3);
             tile_store(t, PU, pfu);
             if constexpr (!FLAT) tile_store(t, PV, pfv);
             tile_store(t, PW, pfw);
+            TSTAMP(4);
             __syncthreads();
+            TSTAMP(5);
         }
     }
+    if constexpr (!DEFW) TSTAMP_FLUSH(0, phi);
 }
 
 // (w, b): same shape, LDS = 2 planes (w and b at the current level)
@@ -678,16 +717,19 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
         tile_fetch(t, ph + (size_t)max(t.k0 - 1, 0) * pl, pfn);
         tile_fetch(t, ph + (size_t)t.k0 * pl, pfp);
     }
-    real winw[6], winb[6], au[6], eu[6], av[6], ev[6];
+    // z windows: w faces and b centres six deep (5-point stencils), the advecting u, v columns four deep (levels k-2..k+1: all the
+    // centred interpolation to the w face reads)
+    real winw[6], winb[6], au[4], eu[4], av[4], ev[4];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        winw[q] = fac(t.k0 - 3 + q); winb[q] = cen(b, col, t.k0 - 3 + q);
-        au[q] = cen(u, col, t.k0 - 4 + q); eu[q] = cen(u, colE, t.k0 - 4 + q);
-        av[q] = FLAT ? real(0.0) : cen(v, col, t.k0 - 4 + q); ev[q] = FLAT ? real(0.0) : cen(v, colN, t.k0 - 4 + q);
+    for (int q = 0; q < 6; ++q) { winw[q] = fac(t.k0 - 3 + q); winb[q] = cen(b, col, t.k0 - 3 + q); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        au[q] = cen(u, col, t.k0 - 3 + q); eu[q] = cen(u, colE, t.k0 - 3 + q);
+        av[q] = FLAT ? real(0.0) : cen(v, col, t.k0 - 3 + q); ev[q] = FLAT ? real(0.0) : cen(v, colN, t.k0 - 3 + q);
     }
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     real nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
-    real nau = cen(u, col, t.k0 + 2), neu = cen(u, colE, t.k0 + 2), nav = FLAT ? real(0.0) : cen(v, col, t.k0 + 2), nev = FLAT ? real(0.0) : cen(v, colN, t.k0 + 2);
+    real nau = cen(u, col, t.k0 + 1), neu = cen(u, colE, t.k0 + 1), nav = FLAT ? real(0.0) : cen(v, col, t.k0 + 1), nev = FLAT ? real(0.0) : cen(v, colN, t.k0 + 1);
     real ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : real(0.0), ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : real(0.0);
     real fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : real(0.0);
     real fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : real(0.0);
@@ -696,25 +738,27 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
     tile_store(t, PW, pfw); tile_store(t, PB, pfb);
     __syncthreads();
 
+    TSTAMP_INIT;
     for (int k = t.k0; k < t.k0 + KT3; ++k) {
         const bool more = (k + 1 < t.k0 + KT3);
+        TSTAMP(6);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            winw[q] = winw[q + 1]; winb[q] = winb[q + 1];
-            au[q] = au[q + 1]; eu[q] = eu[q + 1]; av[q] = av[q + 1]; ev[q] = ev[q + 1];
-        }
+        for (int q = 0; q < 5; ++q) { winw[q] = winw[q + 1]; winb[q] = winb[q + 1]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { au[q] = au[q + 1]; eu[q] = eu[q + 1]; av[q] = av[q + 1]; ev[q] = ev[q + 1]; }
         winw[5] = nw5; winb[5] = nb5;                             // w faces k-2..k+3, b centres k-2..k+3
-        au[5] = nau; eu[5] = neu; av[5] = nav; ev[5] = nev;       // u, v levels k-3..k+2
+        au[3] = nau; eu[3] = neu; av[3] = nav; ev[3] = nev;       // u, v levels k-2..k+1
         const real gpw_ = ngw, gpb_ = ngb;
         if (more) {
             tile_fetch(t, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, b + (size_t)(k + 1) * pl, pfb);
             if constexpr (DEFW) tile_fetch(t, ph + (size_t)(k + 1) * pl, pfn);       // k + 1 <= nz - 1 here
             nw5 = fac(k + 4); nb5 = cen(b, col, k + 4);
-            nau = cen(u, col, k + 3); neu = cen(u, colE, k + 3);
-            if constexpr (!FLAT) { nav = cen(v, col, k + 3); nev = cen(v, colN, k + 3); }
+            nau = cen(u, col, k + 2); neu = cen(u, colE, k + 2);
+            if constexpr (!FLAT) { nav = cen(v, col, k + 2); nev = cen(v, colN, k + 2); }
             if (use_gm) { ngw = gm[eb + 3 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; ngb = gm[eb + (size_t)(k + 1) * pl + col]; }
         }
         __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(0);
         // ---- w at (i, j, z-face k); the wall face k = 0 never evolves ----
         {
             const real w0 = winw[2];
@@ -724,16 +768,16 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
                 real q7[7], c7[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : L(IW, q - 3, 0); c7[q] = (q == 3 || FLAT) ? w0 : L(IW, 0, q - 3); }
-                const real fe = upw(zfS(eu, k, nz), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
-                const real fw = upw(zfS(au, k, nz), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+                const real fe = upw(zfS4(eu, k, nz), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+                const real fw = upw(zfS4(au, k, nz), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
                 real fn = real(0.0), fs = real(0.0);
                 if constexpr (!FLAT) {
-                    fn = upw(zfS(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-                    fs = upw(zfS(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                    fn = upw(zfS4(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+                    fs = upw(zfS4(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
                 }
                 const real adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbw) * rdz;
-                const real vis = nu * ((((eu[3] - eu[2]) * rdz + (q7[4] - w0) * rdx) - ((au[3] - au[2]) * rdz + (w0 - q7[2]) * rdx)) * rdx
-                                         + (((ev[3] - ev[2]) * rdz + (c7[4] - w0) * rdy) - ((av[3] - av[2]) * rdz + (w0 - c7[2]) * rdy)) * rdy
+                const real vis = nu * ((((eu[2] - eu[1]) * rdz + (q7[4] - w0) * rdx) - ((au[2] - au[1]) * rdz + (w0 - q7[2]) * rdx)) * rdx
+                                         + (((ev[2] - ev[1]) * rdz + (c7[4] - w0) * rdy) - ((av[2] - av[1]) * rdz + (w0 - c7[2]) * rdy)) * rdy
                                          + real(2.0) * ((winw[3] - w0) - (w0 - winw[1])) * rdz * rdz);
                 const real G = vis - adv + real(0.5) * (winb[1] + winb[2]);      // + b at the face: the un-split buoyancy term
                 nxt[o] = w0 + dt * (gam * G + zet * gpw_);
@@ -742,18 +786,19 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
             fbw = ft;
         }
         __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(1);
         // ---- b at the centre (i, j, k) ----
         {
             const real b0 = winb[2];
             real q7[7], c7[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : L(IB, q - 3, 0); c7[q] = (q == 3 || FLAT) ? b0 : L(IB, 0, q - 3); }
-            const real fe = upw(eu[3], left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
-            const real fw = upw(au[3], left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const real fe = upw(eu[2], left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
+            const real fw = upw(au[2], left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
             real fn = real(0.0), fs = real(0.0);
             if constexpr (!FLAT) {
-                fn = upw(ev[3], left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-                fs = upw(av[3], left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                fn = upw(ev[2], left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
+                fs = upw(av[2], left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
             }
             real ft = real(0.0), bup;
             if (k + 1 < nz) { ft = upw(winw[3], zfL(winb, k + 1, nz), zfR(winb, k + 1, nz)); bup = winb[3]; }
@@ -767,6 +812,7 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
             if (store_g) gm[o] = G;
             fbb = ft; bdn = b0;
         }
+        TSTAMP(2);
         if (more) {
             if constexpr (DEFW) {
                 tile_correct_w(pfw, pfn, pfp, rdz, dts_prev);
@@ -774,10 +820,14 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
                 for (int q = 0; q < NPF; ++q) pfp[q] = pfn[q];
             }
             __syncthreads();
+            TSTAMP(3);
             tile_store(t, PW, pfw); tile_store(t, PB, pfb);
+            TSTAMP(4);
             __syncthreads();
+            TSTAMP(5);
         }
     }
+    if constexpr (!DEFW) TSTAMP_FLUSH(1, phi);
     if (t.k0 + KT3 == nz) nxt[eb + 3 * (size_t)g.nc + (size_t)nz * pl + col] = real(0.0);      // top wall face
 }
 

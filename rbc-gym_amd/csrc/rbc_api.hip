@@ -319,6 +319,10 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
             CREATE_TRY(hipMemset(h->d_state, 0, B * 5 * h->ncell * sizeof(float)));
         } else CREATE_TRY(hipMalloc(&h->d_state, B * 4 * h->ncell * sizeof(float)));
         h->s3_f32 = (cfg->precision == RBC_PRECISION_F32);
+#if RBC_STAMPS
+        CREATE_TRY(hipMalloc(&h->d_stamps, B * 64 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(h->d_stamps, 0, B * 64 * sizeof(unsigned long long)));
+#endif
         if (int rc = RBC_S3(h, create3d, h)) { rbc_destroy(h); return rc; }
         h->t.assign(B, 0.0);
         h->step.assign(B, 1);
