@@ -527,7 +527,7 @@ def main():
                          "traffic_source": prof_src,
                          "measured_hbm_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                          "measured_hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": f"rbc2d_kernel<96,64,{'float' if f32 else 'double'}>", "kernel_ms_avg": avg_ms,
+                         "kernel": f"rbc2d_kernel<96,64,{'float2 pairs' if f32 else 'double'},DBG=false>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved/frac follow SURVEY.md 8(d)'s convention (algorithmic bytes = 10*F*C*s per RK3 substep, F=3, "
                                  "C=6144, x 50 x batch, / kernel time): a CONVENTION number for this kernel, which keeps the state in LDS "

@@ -66,6 +66,7 @@ struct rbc_handle {
     int nsub = 0;
     double dt_last = 0.0, dt_solver_eff = 0.0;
     void (*kernel)(const rbc::Params2D) = nullptr;
+    void (*kernel_dbg)(const rbc::Params2D) = nullptr;   // the instantiation with the MODE_TENDENCY hook (rbc_debug_tendencies); none for packed pairs
     size_t lds_bytes = 0;
     int threads = 0;
     int lanes = 1;                     // envs per workgroup of the 2D kernel (2 for the packed float32 variant)
@@ -82,6 +83,7 @@ template <int NX, int NZ, typename T>
 void bind_kernel(rbc_handle *h)
 {
     h->kernel = rbc::rbc2d_kernel<NX, NZ, T>;
+    if constexpr (rbc::LaneT<T>::N == 1) h->kernel_dbg = rbc::rbc2d_kernel<NX, NZ, T, true>;
     h->lds_bytes = rbc::Geo<NX, NZ, T>::LDS_BYTES;
     h->threads = rbc::Geo<NX, NZ, T>::NT;
     h->lanes = rbc::LaneT<T>::N;
@@ -169,9 +171,11 @@ rbc::Params2D base_params(const rbc_handle *h)
 
 int launch(rbc_handle *h, const rbc::Params2D &p, bool timed)
 {
+    void (*const kernel)(const rbc::Params2D) = (p.mode == rbc::MODE_TENDENCY) ? h->kernel_dbg : h->kernel;
+    if (!kernel) return fail(RBC_ERR_INVALID, "no kernel for this mode");
     const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
     if (rec) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
-    hipLaunchKernelGGL(h->kernel, dim3((h->B + h->lanes - 1) / h->lanes), dim3(h->threads), h->lds_bytes, h->stream, p);
+    hipLaunchKernelGGL(kernel, dim3((h->B + h->lanes - 1) / h->lanes), dim3(h->threads), h->lds_bytes, h->stream, p);
     HIP_TRY(hipGetLastError());
     if (rec) {
         HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
@@ -346,6 +350,9 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     }
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes));
+    if (h->kernel_dbg)
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(h->kernel_dbg), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)h->lds_bytes));
 #undef CREATE_TRY
     h->t.assign(B, 0.0);
     h->step.assign(B, 1);
