@@ -2,7 +2,7 @@
 """Diagnostic: where a tile workgroup of the 3D tendency kernel spends its level loop (build with -DRBC_STAMPS=1 into a separate
 .so; the shipped library never executes a stamp).  Wave 0 of every workgroup accumulates s_memtime ticks per phase.
     python scripts/tile_stamps.py --build        (here: cross-compiles rbc-gym_amd/lib/librbc_hip_stamps.so)
-    python scripts/tile_stamps.py [f64|f32]      (on the GPU box)
+    python scripts/tile_stamps.py [f64|f32]      (on the GPU box; `2d` : the FLAT tiles of the streaming-2D path at 128 x 64, B = 1024)
 """
 import ctypes as C
 import os, subprocess, sys
@@ -24,11 +24,16 @@ if __name__ == "__main__":
     os.environ.setdefault("RBC_3D_GROUPS", "1")
     from rbc_gym import _native
     prec = 1 if "f32" in sys.argv else 0
-    B = 32
-    sim = _native.NativeSim3D(batch=B, shape=(32, 48, 48), ra=1e4, precision=prec)
+    if "2d" in sys.argv:
+        B = 1024
+        sim = _native.NativeSim(batch=B, nx=128, nz=64, obs_nx=64, obs_nz=8, precision=prec)
+        act = np.random.default_rng(0).uniform(-1, 1, (B, 12)).astype(np.float32)
+    else:
+        B = 32
+        sim = _native.NativeSim3D(batch=B, shape=(32, 48, 48), ra=1e4, precision=prec)
+        act = np.random.default_rng(0).uniform(-1, 1, (B, 8, 8)).astype(np.float32)
     sim.lib.rbc_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     sim.reset(np.arange(B, dtype=np.uint64) + 1234)
-    act = np.random.default_rng(0).uniform(-1, 1, (B, 8, 8)).astype(np.float32)
     for _ in range(3):
         sim.step(act)
     st = np.zeros((B, 64), np.uint64)
