@@ -13,6 +13,24 @@ using rbc::left3; using rbc::left5; using rbc::right3; using rbc::right5; using 
 
 
 __device__ __forceinline__ real upw(real vel, real L, real R) { return vel * (vel > real(0.0) ? L : R); }
+// vel * (the left- or the right-biased fifth-order reconstruction at the face between c | d; a..f = psi[-3..+2]).  float32: both
+// reconstructions as ONE chain of packed instructions -- lane .x the left-biased, lane .y the right-biased one, every tap a
+// v_pk_fma_f32 with the value broadcast to both lanes (op_sel) and the two weights in an SGPR pair: six packed instructions instead
+// of ten scalar ones.  The float32 tile kernels are bound by VALU issue, and these reconstructions are most of their arithmetic.
+template <class R>
+__device__ __forceinline__ R upw5(R vel, R a, R b, R c, R d, R e, R f)
+{
+    if constexpr (std::is_same<R, float>::value) {
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        v2 acc = v2{2.0f / 60.0f, 0.0f} * v2{a, a};
+        acc += v2{-13.0f / 60.0f, -3.0f / 60.0f} * v2{b, b};
+        acc += v2{47.0f / 60.0f, 27.0f / 60.0f} * v2{c, c};
+        acc += v2{27.0f / 60.0f, 47.0f / 60.0f} * v2{d, d};
+        acc += v2{-3.0f / 60.0f, -13.0f / 60.0f} * v2{e, e};
+        acc += v2{0.0f, 2.0f / 60.0f} * v2{f, f};
+        return vel * (vel > 0.0f ? acc.x : acc.y);
+    } else return upw(vel, left5(a, b, c, d, e), right5(b, c, d, e, f));
+}
 
 
 // z (Bounded, N cells).  centre field -> face k: p[j] = psi[k-3+j], j=0..5 (face between p[2] | p[3])
@@ -35,7 +53,6 @@ __device__ __forceinline__ real zcS(const real *p, int k, int N)
 
 __device__ __forceinline__ real l5a(const real *p) { return left5(p[0], p[1], p[2], p[3], p[4]); }
 __device__ __forceinline__ real r5a(const real *p) { return right5(p[1], p[2], p[3], p[4], p[5]); }
-
 // accessor of one env's state buffer
 struct Fields {
     const real *b, *u, *v, *w;
@@ -595,13 +612,13 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             real q7[7], c7[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IU, q - 3, 0); c7[q] = (q == 3 || FLAT) ? f0 : L(IU, 0, q - 3); }
-            const real fe = upw(sym4(q7[2], q7[3], q7[4], q7[5]), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
-            const real fw = upw(sym4(q7[1], q7[2], q7[3], q7[4]), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const real fe = upw5<real>(sym4(q7[2], q7[3], q7[4], q7[5]), q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+            const real fw = upw5<real>(sym4(q7[1], q7[2], q7[3], q7[4]), q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
             real on_m = real(0.0), on_c = real(0.0), os_m = real(0.0), os_c = real(0.0), fn = real(0.0), fs = real(0.0);      // FLAT: v == 0, no y fluxes
             if constexpr (!FLAT) {
                 on_m = L(IV, -1, 1); on_c = L(IV, 0, 1); os_m = L(IV, -1, 0); os_c = winv[2];
-                fn = upw(sym4(L(IV, -2, 1), on_m, on_c, L(IV, 1, 1)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-                fs = upw(sym4(L(IV, -2, 0), os_m, os_c, L(IV, 1, 0)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                fn = upw5<real>(sym4(L(IV, -2, 1), on_m, on_c, L(IV, 1, 1)), c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+                fs = upw5<real>(sym4(L(IV, -2, 0), os_m, os_c, L(IV, 1, 0)), c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
             }
             real ft = real(0.0), dwt = real(0.0), fup;
             if (!top) {
@@ -627,11 +644,11 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             real q7[7], c7[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IV, 0, q - 3); c7[q] = (q == 3) ? f0 : L(IV, q - 3, 0); }
-            const real fe = upw(sym4(q7[2], q7[3], q7[4], q7[5]), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
-            const real fw = upw(sym4(q7[1], q7[2], q7[3], q7[4]), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const real fe = upw5<real>(sym4(q7[2], q7[3], q7[4], q7[5]), q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+            const real fw = upw5<real>(sym4(q7[1], q7[2], q7[3], q7[4]), q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
             const real on_m = L(IU, 1, -1), on_c = L(IU, 1, 0), os_m = L(IU, 0, -1), os_c = winu[2];
-            const real fn = upw(sym4(L(IU, 1, -2), on_m, on_c, L(IU, 1, 1)), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-            const real fs = upw(sym4(L(IU, 0, -2), os_m, os_c, L(IU, 0, 1)), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+            const real fn = upw5<real>(sym4(L(IU, 1, -2), on_m, on_c, L(IU, 1, 1)), c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+            const real fs = upw5<real>(sym4(L(IU, 0, -2), os_m, os_c, L(IU, 0, 1)), c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
             real ft = real(0.0), dwt = real(0.0), fup;
             if (!top) {
                 const real wm = L(IW, 0, -1);
@@ -768,12 +785,12 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
                 real q7[7], c7[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : L(IW, q - 3, 0); c7[q] = (q == 3 || FLAT) ? w0 : L(IW, 0, q - 3); }
-                const real fe = upw(zfS4(eu, k, nz), left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
-                const real fw = upw(zfS4(au, k, nz), left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+                const real fe = upw5<real>(zfS4(eu, k, nz), q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+                const real fw = upw5<real>(zfS4(au, k, nz), q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
                 real fn = real(0.0), fs = real(0.0);
                 if constexpr (!FLAT) {
-                    fn = upw(zfS4(ev, k, nz), left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-                    fs = upw(zfS4(av, k, nz), left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                    fn = upw5<real>(zfS4(ev, k, nz), c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+                    fs = upw5<real>(zfS4(av, k, nz), c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
                 }
                 const real adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbw) * rdz;
                 const real vis = nu * ((((eu[2] - eu[1]) * rdz + (q7[4] - w0) * rdx) - ((au[2] - au[1]) * rdz + (w0 - q7[2]) * rdx)) * rdx
@@ -793,12 +810,12 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
             real q7[7], c7[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : L(IB, q - 3, 0); c7[q] = (q == 3 || FLAT) ? b0 : L(IB, 0, q - 3); }
-            const real fe = upw(eu[2], left5(q7[1], q7[2], q7[3], q7[4], q7[5]), right5(q7[2], q7[3], q7[4], q7[5], q7[6]));
-            const real fw = upw(au[2], left5(q7[0], q7[1], q7[2], q7[3], q7[4]), right5(q7[1], q7[2], q7[3], q7[4], q7[5]));
+            const real fe = upw5<real>(eu[2], q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+            const real fw = upw5<real>(au[2], q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
             real fn = real(0.0), fs = real(0.0);
             if constexpr (!FLAT) {
-                fn = upw(ev[2], left5(c7[1], c7[2], c7[3], c7[4], c7[5]), right5(c7[2], c7[3], c7[4], c7[5], c7[6]));
-                fs = upw(av[2], left5(c7[0], c7[1], c7[2], c7[3], c7[4]), right5(c7[1], c7[2], c7[3], c7[4], c7[5]));
+                fn = upw5<real>(ev[2], c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+                fs = upw5<real>(av[2], c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
             }
             real ft = real(0.0), bup;
             if (k + 1 < nz) { ft = upw(winw[3], zfL(winb, k + 1, nz), zfR(winb, k + 1, nz)); bup = winb[3]; }
