@@ -528,12 +528,22 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
     // sit alone on their SIMDs and the phase is bound by their instruction count.
     constexpr int BLK = G::ZBLK;                               // rows fetched ahead of the recurrence
     static_assert(HALF % BLK == 0 && TSPLIT % BLK == 0, "z-sweep blocks must not straddle the table split");
+    // A ds instruction's immediate offset is 16 bits: from ONE base register only the first RPB rows of a column are reachable
+    // (28 at 96 float64 columns), and hipcc spends a v_add_u32 on every access beyond -- two per row in the down sweep, whose rows
+    // all lie beyond, in a phase that four lone waves issue instruction by instruction.  Opaque per-base offsets give every
+    // block of RPB rows its own base register, computed once per sweep.
+    constexpr int RPB = 65535 / (RS * (int)sizeof(T));
+    constexpr int NBASE = (NZ + RPB - 1) / RPB;
+    int rbase[NBASE];
+#pragma unroll
+    for (int q = 0; q < NBASE; ++q) rbase[q] = (q == 0) ? 0 : opaque(q * RPB * RS);
+    auto row = [&](int k) -> T & { return colb[rbase[k / RPB] + (k % RPB) * RS]; };
     auto fwd = [&](auto dir) {
         constexpr int DIR = decltype(dir)::value;
         T y = T(0);
         T rr[BLK], tt[BLK];
 #pragma unroll
-        for (int j = 0; j < BLK; ++j) { rr[j] = colb[(DIR > 0 ? j : NZ - 1 - j) * RS]; tt[j] = (j < TSPLIT ? tabA : tabB)[j * G::NH + tm]; }
+        for (int j = 0; j < BLK; ++j) { rr[j] = row(DIR > 0 ? j : NZ - 1 - j); tt[j] = (j < TSPLIT ? tabA : tabB)[j * G::NH + tm]; }
 #pragma unroll
         for (int s0 = 0; s0 < HALF; s0 += BLK) {
             T rn[BLK], tn[BLK];
@@ -541,14 +551,14 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {
                     const int sidx = s0 + BLK + j;
-                    rn[j] = colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS];
+                    rn[j] = row(DIR > 0 ? sidx : NZ - 1 - sidx);
                     tn[j] = (sidx < TSPLIT ? tabA : tabB)[sidx * G::NH + tm];
                 }
             }
 #pragma unroll
             for (int j = 0; j < BLK; ++j) {
                 y = tt[j] * (rr[j] - cpf * y);                       // y_k = (r_k - c y_{k-1}) / piv_k
-                colb[(DIR > 0 ? s0 + j : NZ - 1 - s0 - j) * RS] = y;
+                row(DIR > 0 ? s0 + j : NZ - 1 - s0 - j) = y;
             }
             if (s0 + BLK < HALF) {
 #pragma unroll
@@ -568,13 +578,13 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
         const T jf = (HALF < TSPLIT ? tabA : tabB)[HALF * G::NH + tm];   // 1/(1-c^2); 0 for the singular mean mode
         T x = DIR > 0 ? (ya - c * yb) * jf : (yb - c * ya) * jf;
         if (tm == 0) x = DIR > 0 ? ya : T(0);                                  // pin the mean mode (mean removed on output)
-        colb[(DIR > 0 ? HALF - 1 : HALF) * RS] = x;
+        row(DIR > 0 ? HALF - 1 : HALF) = x;
         // rows HALF-2 .. 0 (sweep-local numbering), fetched BLK ahead; the first block is one row short
         T yy[BLK], cc[BLK];
 #pragma unroll
         for (int j = 0; j < BLK; ++j) {
             const int sidx = HALF - 2 - j;
-            yy[j] = colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS];
+            yy[j] = row(DIR > 0 ? sidx : NZ - 1 - sidx);
             cc[j] = (sidx < TSPLIT ? tabA : tabB)[sidx * G::NH + tm];
         }
 #pragma unroll
@@ -584,7 +594,7 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
             for (int j = 0; j < BLK; ++j) {
                 const int sidx = s0 - BLK - j;
                 if (sidx >= 0) {
-                    yn[j] = colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS];
+                    yn[j] = row(DIR > 0 ? sidx : NZ - 1 - sidx);
                     cn[j] = (sidx < TSPLIT ? tabA : tabB)[sidx * G::NH + tm];
                 }
             }
@@ -593,7 +603,7 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
                 const int sidx = s0 - j;
                 if (sidx >= 0) {
                     x = yy[j] - (cc[j] * cpf) * x;
-                    colb[(DIR > 0 ? sidx : NZ - 1 - sidx) * RS] = x;
+                    row(DIR > 0 ? sidx : NZ - 1 - sidx) = x;
                 }
             }
 #pragma unroll
