@@ -19,8 +19,8 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.p
 BOUNDS = {
     # LDS-resident 2D kernels: one 12-wave workgroup per CU -> 168 VGPRs is the cap for 3 waves per SIMD
     # (the production instantiations: DBG = false, no MODE_TENDENCY hook)
-    "rbc::rbc2d_kernel<96, 64, double, false>": (168, 4, 43, 20),
-    "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 42, 85, 92),
+    "rbc::rbc2d_kernel<96, 64, double, false>": (168, 0, 43, 0),             # no scratch at all since round 3
+    "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 20, 85, 44),
     # 3D tendency tiles, configs[4]'s 48 x 48 planes as compile-time constants (12 waves, 3 per SIMD).  NO spill: a reload from
     # scratch shares vmcnt with the planes prefetched one level ahead and waits for them -- six spilled VGPRs cost 7 % of the
     # env-step rate until round 3 (scripts/tile_stamps.py)
