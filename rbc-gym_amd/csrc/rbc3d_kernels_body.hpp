@@ -1617,16 +1617,38 @@ __global__ void __launch_bounds__(N1 >= 32 ? 256 : 512) k2s_project_fused(Geo3 g
     real *sb = st + (size_t)env * g.env_stride;
     real *u = sb + g.nc, *w = sb + 3 * (size_t)g.nc;
     const real rdt = real(1.0) / dts;
-    for (int idx = tid; idx < half * nx; idx += nthr) {
-        const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
-        const int ip = (i + 1 == nx) ? 0 : i + 1;
-        auto div = [&](int kk) -> real {
-            const size_t c = (size_t)kk * nx;
-            const real wt = (kk + 1 < nz) ? w[c + nx + i] : real(0.0);
-            const real wb = (kk > 0) ? w[c + i] : real(0.0);
-            return (u[c + ip] - u[c + i]) * g.rdx + (wt - wb) * g.rdz;
-        };
-        A[r * ls + i] = make_real2(div(r) * rdt, div(km) * rdt);
+    // The loops over an env's cells below run 8-16 trips per thread with global loads in every trip; trip by trip each load's
+    // round trip is exposed (hipcc does not pipeline them: the trip count is a run-time value), and these loops were most of the
+    // kernel's 42 us.  Every loop therefore works on UB trips at once: all their loads first, then the arithmetic and the stores.
+    constexpr int UB = 4;
+    for (int base = tid; base < half * nx; base += nthr * UB) {
+        real uE[UB][2], uC[UB][2], wT[UB][2], wB[UB][2];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+            const int idx = base + q * nthr;
+            if (idx < half * nx) {
+                const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
+                const int ip = (i + 1 == nx) ? 0 : i + 1;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int kk = h2 ? km : r;
+                    const size_t c = (size_t)kk * nx;
+                    uE[q][h2] = u[c + ip]; uC[q][h2] = u[c + i];
+                    wT[q][h2] = (kk + 1 < nz) ? w[c + nx + i] : real(0.0);
+                    wB[q][h2] = (kk > 0) ? w[c + i] : real(0.0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+            const int idx = base + q * nthr;
+            if (idx < half * nx) {
+                const int r = idx / nx, i = idx - r * nx;
+                const real d0 = (uE[q][0] - uC[q][0]) * g.rdx + (wT[q][0] - wB[q][0]) * g.rdz;
+                const real d1 = (uE[q][1] - uC[q][1]) * g.rdx + (wT[q][1] - wB[q][1]) * g.rdz;
+                A[r * ls + i] = make_real2(d0 * rdt, d1 * rdt);
+            }
+        }
     }
     __syncthreads();
     rowfft_inplace<N1>(A, half, ls, twx, -1);
@@ -1698,17 +1720,45 @@ __global__ void __launch_bounds__(N1 >= 32 ? 256 : 512) k2s_project_fused(Geo3 g
     // corrections (same operation order as k3_ifft_pair / k3_correct_w: differences of the normalised potentials)
     const real sc = real(1.0) / (real)nx;
     real *ph = phi + (size_t)env * g.nc;
-    for (int idx = tid; idx < half * nx; idx += nthr) {
-        const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
-        const real2 c = A[r * ls + i], pw = A[r * ls + ((i == 0) ? nx - 1 : i - 1)];
-        u[(size_t)r * nx + i] -= (c.x * sc - pw.x * sc) * g.rdx * dts;
-        u[(size_t)km * nx + i] -= (c.y * sc - pw.y * sc) * g.rdx * dts;
-        if (store_phi) { ph[(size_t)r * nx + i] = c.x * sc; ph[(size_t)km * nx + i] = c.y * sc; }
+    for (int base = tid; base < half * nx; base += nthr * UB) {
+        real u0[UB], u1[UB];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+            const int idx = base + q * nthr;
+            if (idx < half * nx) {
+                const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
+                u0[q] = u[(size_t)r * nx + i]; u1[q] = u[(size_t)km * nx + i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+            const int idx = base + q * nthr;
+            if (idx < half * nx) {
+                const int r = idx / nx, i = idx - r * nx, km = nz - 1 - r;
+                const real2 c = A[r * ls + i], pw = A[r * ls + ((i == 0) ? nx - 1 : i - 1)];
+                u[(size_t)r * nx + i] = u0[q] - (c.x * sc - pw.x * sc) * g.rdx * dts;
+                u[(size_t)km * nx + i] = u1[q] - (c.y * sc - pw.y * sc) * g.rdx * dts;
+                if (store_phi) { ph[(size_t)r * nx + i] = c.x * sc; ph[(size_t)km * nx + i] = c.y * sc; }
+            }
+        }
     }
     auto phi_at = [&](int cell, int i) -> real { return (cell < half) ? A[cell * ls + i].x : A[(nz - 1 - cell) * ls + i].y; };
-    for (int idx = tid; idx < (nz - 1) * nx; idx += nthr) {
-        const int f = idx / nx + 1, i = idx - (f - 1) * nx;                           // face f between cells f-1 and f
-        w[(size_t)f * nx + i] -= (phi_at(f, i) * sc - phi_at(f - 1, i) * sc) * g.rdz * dts;
+    constexpr int WB = 8;
+    for (int base = tid; base < (nz - 1) * nx; base += nthr * WB) {
+        real w0[WB];
+#pragma unroll
+        for (int q = 0; q < WB; ++q) {
+            const int idx = base + q * nthr;
+            if (idx < (nz - 1) * nx) w0[q] = w[(size_t)nx + idx];                       // face f = idx / nx + 1, column i: offset f * nx + i
+        }
+#pragma unroll
+        for (int q = 0; q < WB; ++q) {
+            const int idx = base + q * nthr;
+            if (idx < (nz - 1) * nx) {
+                const int f = idx / nx + 1, i = idx - (f - 1) * nx;                   // face f between cells f-1 and f
+                w[(size_t)nx + idx] = w0[q] - (phi_at(f, i) * sc - phi_at(f - 1, i) * sc) * g.rdz * dts;
+            }
+        }
     }
 }
 

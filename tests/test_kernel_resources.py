@@ -31,7 +31,7 @@ BOUNDS = {
     "rbc3::k3_tile_all<16, 4, 2, 768, 3, 64, false, 48, 48, false>": (168, 0, 0, 0),
     # streaming-2D: FLAT tiles and the one-kernel projection at 128 x 64 (N1 = 16, two workgroups per CU)
     "rbc3::k3_tile_all<1, 16, 1, 256, 3, 256, true, 0, 0, false>": (128, 0, 0, 0),
-    "rbc3::k2s_project_fused<16>": (100, 0, 0, 0),
+    "rbc3::k2s_project_fused<16>": (104, 0, 0, 0),
     # projection kernels of the 3D path
     "rbc3::k3_rhs_fft_pair": (64, 0, 0, 0),
     "rbc3::k3_ifft_pair": (72, 0, 0, 0),
