@@ -552,7 +552,7 @@ def main():
                 extra["gym_api_env_steps_per_s"] = {
                     "no_info_state": gym_api_rate(ctx, B, 5, False), "pinned_info_state": gym_api_rate(ctx, B, 5, "pinned"),
                     "note": "B x VectorEnv.step() per wall second, host actions in, host obs/reward/info out; 5 steps after 1 warm-up"}
-                d3 = run_3d(ctx, 32, 10, 3, 1e4)
+                d3 = run_3d(ctx, 32, 40, 5, 1e4)
                 extra["config4_3d"] = {k: d3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                           "nan_envs", "mean_nusselt")}
                 extra["gym_api_3d_env_steps_per_s"] = {
@@ -560,7 +560,7 @@ def main():
                     "pinned_buffers_fp32": gym_api_rate_3d(ctx, 32, 8, "pinned", "f32") if _native.has_precision("f32") else None,
                     "note": "configs[4], B x VectorEnv.step() per wall second with the 38 MB of float32 observations crossing PCIe every step; 8 steps after 1 warm-up"}
                 if _native.has_precision("f32"):           # the float32 instantiation of the same 3D kernels (153 MB algorithmic per env-step)
-                    d3f = run_3d(ctx, 32, 10, 3, 1e4, "f32")
+                    d3f = run_3d(ctx, 32, 40, 5, 1e4, "f32")
                     extra["config4_3d_fp32"] = {k: d3f[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
                                                                     "roofline", "nan_envs", "mean_nusselt")}
                 if not f32 and _native.has_precision("f32"):
