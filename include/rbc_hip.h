@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBC_ABI_VERSION 2
+#define RBC_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -72,9 +72,24 @@ typedef struct rbc_config {
                                 float32 observations anyway).  The I/O types of the ABI do not change with it (float64
                                 fields in and out, float32 obs/state; Nusselt sums stay float64); only rbc_dev_fields()
                                 exposes the solver's own element type (float for a float32 streaming / 3D handle).  */
+    int32_t reference_clock; /* how many solver steps an env-step integrates (ABI 3).
+                                RBC_CLOCK_DOCUMENTED (0, default): what the reference's SOURCES say -- run!(simulation) to
+                                stop_time, stop_time += dt (rbc_sim2D_api.jl:84-85, rbc_sim3D_api.jl:88-89): every env-step
+                                integrates dt_control, i.e. ceil(dt_control / dt_solver) solver steps.
+                                RBC_CLOCK_RECORDED (1): what the reference's only RECORDED time series shows
+                                (experiments/flowstats/flowstats_ra.pkl, written by flowstats_ra.py:55-66 through
+                                rbc_sim3D_api.jl:77-101): the first env-step after a reset carries the growth of all its
+                                solver steps, every later one of one solver step less (tau(n) = 1 + 0.98 (n - 1) at 50
+                                solver steps per env-step on all four series).  With this value the
+                                first rbc_step after a reset of an env integrates dt_control and every later one
+                                dt_control - dt_solver (one full solver step dropped, a clipped last substep kept), while
+                                t and step reported by rbc_get_info advance as documented.  Per env: a masked reset
+                                restores the full first interval for the envs it resets, whatever the others are doing.
+                                Needs dt_control > dt_solver.  dim = 2 and 3, every precision and path.                */
 } rbc_config;
 
 enum { RBC_PRECISION_F64 = 0, RBC_PRECISION_F32 = 1 };
+enum { RBC_CLOCK_DOCUMENTED = 0, RBC_CLOCK_RECORDED = 1 };
 
 typedef struct rbc_handle rbc_handle;
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ float obs_value(const Params2D &P, int c, double x)
     float o = (float)x;
     if (c < P.obs_norm) {
         o = __fmul_rn(P.obs_maxval, __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(o, P.obs_min[c])), P.obs_rng[c]), 1.0f));
-        if (P.obs_clip) o = fminf(fmaxf(o, -P.obs_maxval), P.obs_maxval);
+        if (P.obs_clip && o == o) o = fminf(fmaxf(o, -P.obs_maxval), P.obs_maxval);      // (a NaN goes through, as in np.clip)
     }
     return o;
 }

@@ -6,6 +6,7 @@
 namespace RBC3_HOST {
 
 namespace K3 = RBC3_NS;
+namespace K3C = rbc3c;
 using real = K3::real;
 using real2 = K3::real2;
 
@@ -35,12 +36,14 @@ struct rbc3_state {
     size_t fuse2d_lds = 0;
     int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
     double tff = 1.0;
-    // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" overrides them for the
-    // "does the flowstats pin discriminate the time integrator" experiment; never set in production.
+    // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  Builds made with -DRBC_EXPERIMENTS=1 (never the shipped library) read
+    // RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" for the "does the flowstats pin discriminate the time integrator" experiment.
     double gam[3] = {8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0}, zet[3] = {0.0, -17.0 / 60.0, -5.0 / 12.0};
     // one captured HIP graph per ping-pong parity of the standard env-step (39 stages is odd, so the
     // starting buffer alternates): ~350 launches replayed as one graph launch
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    // (second index: 0 = the handle's nsub solver steps, 1 = nsub - 1, the later env-steps of RBC_CLOCK_RECORDED)
+    hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    real *lead_save = nullptr;         // RBC_CLOCK_RECORDED, mixed batches: the envs that sit out the fresh envs' extra solver step
     // env groups: the batch is cut into `groups` contiguous ranges and every range runs its own chain of stage kernels on its
     // own stream (envs are independent), so that one group's latency-bound phases (single-round FFT launches, kernel tails)
     // overlap another group's tendency kernels.  1 = the whole batch on the handle's stream.
@@ -110,29 +113,35 @@ int create3d(rbc_handle *h)
     g.heaters = c.heaters;
     g.wall_nx = h->stream2d ? c.nx : 0;
     s->tff = h->stream2d ? 1.0 : c.lz * c.lz;                // rbc_sim3D_api.jl:43
+#if RBC_EXPERIMENTS           /* numerics-changing knob: only in builds made with -DRBC_EXPERIMENTS=1, never in the shipped library */
     if (const char *e = std::getenv("RBC_EXPERIMENT_RK3")) {
         double v[5];
         if (std::sscanf(e, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
             s->gam[0] = v[0]; s->gam[1] = v[1]; s->gam[2] = v[2]; s->zet[1] = v[3]; s->zet[2] = v[4];
         } else return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_RK3 must be g1,g2,g3,z2,z3");
     }
+#endif
     factor2(c.nx, s->plan.nx1, s->plan.nx2);
     factor2(ny, s->plan.ny1, s->plan.ny2);
     s->fft_lds = ((size_t)2 * K3::slab_row(c.nx) * ny + c.nx + ny) * sizeof(real2);
     { const int items = 8 * (c.nx > ny ? c.nx : ny); s->fft_threads = items >= 512 ? 512 : (items <= 256 ? 256 : (items + 63) / 64 * 64); }
     if (h->stream2d) s->fft_threads = c.nx >= 256 ? 256 : (c.nx + 63) / 64 * 64;      // a "slab" is one row: one work item per point
+#if RBC_EXPERIMENTS
     if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_THREADS")) {            // A/B knob of the slab-FFT workgroup size
         const int v = std::atoi(e);
         if (v < 64 || v > 1024 || v % 64) return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_FFT_THREADS must be a multiple of 64 in [64, 1024]");
         s->fft_threads = v;
     }
+#endif
     if (h->stream2d && c.nz % 2 == 0 && !h->no_pair) {      // several row pairs per workgroup (k2s_rhs_fft_pair / k2s_ifft_pair)
         int R = 16;
+#if RBC_EXPERIMENTS
         if (const char *e = std::getenv("RBC_EXPERIMENT_FFT_ROWS")) {
             R = std::atoi(e);
             if (R < 1 || R > 64 || (R & (R - 1))) return fail(RBC_ERR_INVALID, "RBC_EXPERIMENT_FFT_ROWS must be a power of two in [1, 64]");
         }
         if (const char *e = std::getenv("RBC_EXPERIMENT_FFT2D_THREADS")) s->thr2d = std::atoi(e);
+#endif
         if (s->thr2d > 256 || s->thr2d < 64) s->thr2d = 256;          // the kernels' launch bound
         while (R > 1 && ((c.nz / 2) % R != 0 || (size_t)(2 * R * K3::slab_row(c.nx) + c.nx) * sizeof(real2) > 128 * 1024)) R /= 2;
         s->rows2d = R < 1 ? 1 : R;
@@ -262,8 +271,9 @@ void drop_graphs3d(rbc_handle *h)
 {
     if (!h->s3) return;
     (void)hipStreamSynchronize(h->stream);
-    for (auto &g : S3(h)->gexec)
-        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &gp : S3(h)->gexec)
+        for (auto &g : gp)
+            if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
 }
 
 void destroy3d(rbc_handle *h)
@@ -274,7 +284,7 @@ void destroy3d(rbc_handle *h)
     for (hipStream_t q : s->gstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : s->gdone) if (e) (void)hipEventDestroy(e);
     if (s->gstart) (void)hipEventDestroy(s->gstart);
-    void *bufs[] = {s->st[0], s->st[1], s->gm, s->phy, s->phy2, s->tab_perm, s->partner, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
+    void *bufs[] = {s->st[0], s->st[1], s->lead_save, s->gm, s->phy, s->phy2, s->tab_perm, s->partner, s->phi, s->spec, s->jct, s->tw, s->actT, s->tab, s->dbg, s->out_part, s->out_arrive};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -528,7 +538,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
 
 // advance + outputs for the whole batch: every env group's chain on its own stream, forked from and joined back into the
 // handle's stream (the same calls capture into a graph)
-int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last)
+int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double dt_last, bool with_output = true)
 {
     rbc3_state *s = S3(h);
     int which = s->cur;
@@ -539,7 +549,7 @@ int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, dou
         if (s->groups <= 1) {
             const rbc3_grp q{s0, Bs, h->stream};
             if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
-            if (int rc = output3d(h, q, which, nullptr)) return rc;
+            if (with_output) if (int rc = output3d(h, q, which, nullptr)) return rc;
             continue;
         }
         HIP3(hipEventRecord(s->gstart, h->stream));
@@ -550,7 +560,7 @@ int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, dou
             const rbc3_grp q{e0, Bg, s->gstream[gi]};
             HIP3(hipStreamWaitEvent(q.st, s->gstart, 0));
             if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
-            if (int rc = output3d(h, q, which, nullptr)) return rc;
+            if (with_output) if (int rc = output3d(h, q, which, nullptr)) return rc;
             HIP3(hipEventRecord(s->gdone[gi], q.st));
             HIP3(hipStreamWaitEvent(h->stream, s->gdone[gi], 0));
         }
@@ -564,7 +574,9 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
     rbc3_state *s = S3(h);
     const bool rec = timed && h->profiling && 2 * (h->ev_used + 1) <= h->ev.size();
     // (the legacy default stream -- rbc_set_stream(h, hipStreamLegacy) -- cannot be captured: direct launches there)
-    const bool standard = (nsub == h->nsub) && (dt == h->dt_solver_eff) && (dt_last == h->dt_last) && !h->no_graph &&
+    const bool recorded = (h->cfg.reference_clock == RBC_CLOCK_RECORDED);
+    const int var = (nsub == h->nsub) ? 0 : ((recorded && nsub == h->nsub - 1) ? 1 : -1);      // which captured graph this step is
+    const bool standard = (var >= 0) && (dt == h->dt_solver_eff) && (dt_last == h->dt_last) && !h->no_graph &&
                           h->stream != nullptr && h->stream != hipStreamPerThread;      // (legacy = the null stream here, see rbc_set_stream)
     if (standard && actions_dev != h->d_actions)     // the graph reads the handle's own action buffer
         HIP3(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->B * (h->stream2d ? 1 : s->g.heaters) * s->g.heaters * sizeof(float),
@@ -572,7 +584,7 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
     if (rec) HIP3(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
     if (standard) {
         const int par = s->cur;
-        if (!s->gexec[par]) {
+        if (!s->gexec[par][var]) {
             hipGraph_t graph = nullptr;
             HIP3(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
             int rc = run_step3d(h, h->d_actions, nsub, dt, dt_last);
@@ -580,10 +592,10 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
             s->cur = par;                               // capture executed nothing: undo the host-side flips
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return fail(RBC_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            HIP3(hipGraphInstantiate(&s->gexec[par], graph, nullptr, nullptr, 0));
+            HIP3(hipGraphInstantiate(&s->gexec[par][var], graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);
         }
-        HIP3(hipGraphLaunch(s->gexec[par], h->stream));
+        HIP3(hipGraphLaunch(s->gexec[par][var], h->stream));
         s->cur = par ^ ((3 * nsub) & 1);
     } else {
         if (int rc = run_step3d(h, actions_dev, nsub, dt, dt_last)) return rc;
@@ -592,6 +604,25 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
         HIP3(hipEventRecord(h->ev[2 * h->ev_used + 1], h->stream));
         h->ev_used++;
     }
+    return RBC_OK;
+}
+
+// RBC_CLOCK_RECORDED with a mixed batch: one solver step for the envs marked in `fresh_dev` only.  The stage kernels have no env
+// mask, so the whole batch takes the step (same env groups, hence the same tile instantiations, as an env-step) and the envs that
+// were not marked get their state back afterwards; the marked ones are then exactly -- bit for bit -- where the first substep of
+// a full interval would have put them.
+int lead_substep3d(rbc_handle *h, const float *actions_dev, const uint8_t *fresh_dev)
+{
+    rbc3_state *s = S3(h);
+    const size_t n = (size_t)h->B * s->g.env_stride;
+    if (!s->lead_save) HIP3(hipMalloc(&s->lead_save, n * sizeof(real)));
+    HIP3(hipMemcpyAsync(s->lead_save, s->st[s->cur], n * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
+    if (int rc = run_step3d(h, actions_dev, 1, h->dt_solver_eff, h->dt_solver_eff, false)) return rc;
+    const int which = s->cur;
+    const size_t words = s->g.env_stride * (sizeof(real) / 4);
+    hipLaunchKernelGGL(K3C::k3_restore_unmarked, dim3((unsigned)h->B, 64), dim3(256), 0, h->stream, reinterpret_cast<uint32_t *>(s->st[which]),
+                       reinterpret_cast<const uint32_t *>(s->lead_save), fresh_dev, words);
+    HIP3(hipGetLastError());
     return RBC_OK;
 }
 

@@ -112,6 +112,16 @@ __global__ void __launch_bounds__(128) k2s_wall(Geo3 g, const float *actions, do
     wall[(size_t)env * g.nx + i] = Tb;
 }
 
+// state of every env NOT marked in `mark` copied back from `src` (host3::lead_substep3d); 4-byte words, blockIdx.x = env
+__global__ void __launch_bounds__(256) k3_restore_unmarked(uint32_t *dst, const uint32_t *src, const uint8_t *mark, size_t words_per_env)
+{
+    const int env = blockIdx.x;
+    if (mark[env]) return;
+    const size_t base = (size_t)env * words_per_env;
+    for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < words_per_env; i += (size_t)gridDim.y * blockDim.x)
+        dst[base + i] = src[base + i];
+}
+
 // RBCNormalizeObservation fused into the 3D output kernel's float32 state write (the 3D observation IS the state, rbc3D.py:229-232):
 // obs[c] <- maxval * (2 * (obs[c] - min[c]) / (max[c] - min[c]) - 1), optionally clipped -- the same float32 operations in the same
 // order as the numpy expression of rbc_normalize_observation.py:66-74 (no contraction), so results are bit-identical to the host wrapper.
@@ -123,7 +133,7 @@ __device__ __forceinline__ float obs_value3(const ObsNorm3 &P, int c, float o)
 {
     if (c < P.n) {
         o = __fmul_rn(P.maxval, __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(o, P.mn[c])), P.rng[c]), 1.0f));
-        if (P.clip) o = fminf(fmaxf(o, -P.maxval), P.maxval);
+        if (P.clip && o == o) o = fminf(fmaxf(o, -P.maxval), P.maxval);      // np.clip hands a NaN through; fminf / fmaxf would drop it
     }
     return o;
 }
@@ -141,7 +151,7 @@ __device__ __forceinline__ float obs_value2(const Out2D &P, int c, double x)
     float o = (float)x;
     if (c < P.obs_norm) {      // RBCNormalizeObservation, same float32 operations as rbc::obs_value
         o = __fmul_rn(P.obs_maxval, __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(o, P.obs_min[c])), P.obs_rng[c]), 1.0f));
-        if (P.obs_clip) o = fminf(fmaxf(o, -P.obs_maxval), P.obs_maxval);
+        if (P.obs_clip && o == o) o = fminf(fmaxf(o, -P.obs_maxval), P.obs_maxval);      // (NaN goes through, as in np.clip)
     }
     return o;
 }

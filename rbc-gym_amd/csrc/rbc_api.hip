@@ -16,6 +16,13 @@
 #include <string>
 #include <vector>
 
+// -DRBC_EXPERIMENTS=1: A/B builds made by scripts/ that read the numerics- or launch-shape-changing RBC_EXPERIMENT_* environment
+// variables (rbc3d_host_body.hpp).  The shipped library is built without it and contains none of them
+// (tests/test_host_api.py::test_shipped_library_has_no_experiment_knobs).
+#ifndef RBC_EXPERIMENTS
+#define RBC_EXPERIMENTS 0
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -60,6 +67,7 @@ struct rbc_handle {
     std::vector<int64_t> step;
     std::vector<uint8_t> inited;
     std::vector<double> stage;        // host staging for reset_from_arrays
+    std::vector<uint8_t> fresh;       // RBC_CLOCK_RECORDED: envs whose next env-step is the first after their reset (staging of d_mask)
     std::vector<hipEvent_t> ev;       // profiling: (start, stop) pairs, one pair per timed launch
     size_t ev_used = 0;               // pairs recorded since the last rbc_profile_read
     bool profiling = false;
@@ -234,6 +242,7 @@ void rbc_default_config(rbc_config *c)
     c->obs_nx = 48; c->obs_nz = 8;
     c->batch = 1; c->device = 0; c->write_state = 1;
     c->precision = RBC_PRECISION_F64;
+    c->reference_clock = RBC_CLOCK_DOCUMENTED;
 }
 
 int rbc_create(const rbc_config *cfg, rbc_handle **out)
@@ -244,6 +253,8 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
     if (cfg->dim != 2 && cfg->dim != 3) return fail(RBC_ERR_INVALID, "dim must be 2 or 3");
     if (cfg->batch < 1) return fail(RBC_ERR_INVALID, "batch must be >= 1");
     if (!rbc_has_precision(cfg->precision)) return fail(RBC_ERR_INVALID, "precision must be RBC_PRECISION_F64 or RBC_PRECISION_F32");
+    if (cfg->reference_clock != RBC_CLOCK_DOCUMENTED && cfg->reference_clock != RBC_CLOCK_RECORDED)
+        return fail(RBC_ERR_INVALID, "reference_clock must be RBC_CLOCK_DOCUMENTED or RBC_CLOCK_RECORDED");
     if (cfg->heaters < 1 || cfg->heaters > rbc::MAX_HEATERS) return fail(RBC_ERR_INVALID, "heaters out of range");
     if (!(cfg->ra > 0) || !(cfg->pr > 0) || !(cfg->dt_solver > 0) || !(cfg->dt_control > 0))
         return fail(RBC_ERR_INVALID, "ra, pr, dt_solver, dt_control must be positive");
@@ -284,6 +295,11 @@ int rbc_create(const rbc_config *cfg, rbc_handle **out)
         if (rem > 1e-9 * dt) { h->nsub = nfull + 1; h->dt_last = rem; }
         else { h->nsub = nfull; h->dt_last = dt; }
         if (h->nsub < 1) { delete h; return fail(RBC_ERR_INVALID, "dt_control shorter than one solver step"); }
+        // RBC_CLOCK_RECORDED drops one FULL solver step from every env-step but the first after a reset
+        if (cfg->reference_clock == RBC_CLOCK_RECORDED && (h->nsub < 2 || !(T - dt > 1e-9 * dt))) {
+            delete h;
+            return fail(RBC_ERR_INVALID, "reference_clock = RBC_CLOCK_RECORDED needs dt_control > dt_solver");
+        }
     }
 
 #define CREATE_TRY(expr)                                                                           \
@@ -532,20 +548,49 @@ static void advance_clocks(rbc_handle *h)
     }
 }
 
+// One env-step of the 2D resident kernel or of the streaming path: `nsub` solver steps for every env (the last of size dt_last).
+static int step_uniform(rbc_handle *h, const float *actions_dev, int nsub, bool timed)
+{
+    if (h->s3) return RBC_S3(h, step3d, h, actions_dev, nsub, h->dt_solver_eff, h->dt_last, timed);
+    rbc::Params2D p = base_params(h);
+    p.actions = actions_dev;
+    p.nsub = nsub;
+    return launch(h, p, timed);
+}
+
 int rbc_step_dev(rbc_handle *h, const float *actions_dev)
 {
     if (int rc = check_handle(h)) return rc;
     if (int rc = all_initialized(h)) return rc;
     if (!actions_dev) return fail(RBC_ERR_INVALID, "null actions");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    if (h->s3) {
-        if (int rc = RBC_S3(h, step3d, h, actions_dev, h->nsub, h->dt_solver_eff, h->dt_last, true)) return rc;
+    if (h->cfg.reference_clock == RBC_CLOCK_RECORDED) {
+        // The reference's recorded series (rbc_config.reference_clock): the first env-step after a reset integrates all
+        // nsub solver steps, every later one nsub - 1.  step[e] == 1 (api:67) marks an env that has not stepped since its reset.
+        int nfresh = 0;
+        h->fresh.resize(h->B);
+        for (int e = 0; e < h->B; ++e) { h->fresh[e] = (h->step[e] == 1); nfresh += h->fresh[e]; }
+        if (nfresh == h->B) { if (int rc = step_uniform(h, actions_dev, h->nsub, true)) return rc; }
+        else if (nfresh == 0) { if (int rc = step_uniform(h, actions_dev, h->nsub - 1, true)) return rc; }
+        else {
+            // mixed batch (a masked reset put some envs at their first env-step): the fresh envs take their extra solver step
+            // alone -- the same arithmetic as the first substep of a full interval, nothing is carried from one RK3 substep
+            // into the next (zeta^1 = 0) --, then every env runs the nsub - 1 steps of a later interval
+            HIP_TRY(hipMemcpyAsync(h->d_mask, h->fresh.data(), (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+            if (h->s3) { if (int rc = RBC_S3(h, lead_substep3d, h, actions_dev, h->d_mask)) return rc; }
+            else {
+                rbc::Params2D p = base_params(h);
+                p.actions = actions_dev;
+                p.nsub = 1; p.dt_last = h->cfg.dt_solver;
+                p.mask = h->d_mask;
+                if (int rc = launch(h, p, false)) return rc;
+            }
+            if (int rc = step_uniform(h, actions_dev, h->nsub - 1, true)) return rc;
+        }
         advance_clocks(h);
         return RBC_OK;
     }
-    rbc::Params2D p = base_params(h);
-    p.actions = actions_dev;
-    if (int rc = launch(h, p, true)) return rc;
+    if (int rc = step_uniform(h, actions_dev, h->nsub, true)) return rc;
     advance_clocks(h);
     return RBC_OK;
 }

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(_PKG)                      # rbc-gym_amd/
 LIB_PATH = os.path.join(ROOT, "lib", "librbc_hip.so")
 
 RBC_OK, RBC_ERR_INVALID, RBC_ERR_DEVICE, RBC_ERR_NAN, RBC_ERR_NOT_INITIALIZED = range(5)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RbcConfig(C.Structure):
@@ -29,9 +29,22 @@ class RbcConfig(C.Structure):
                 ("dt_solver", C.c_double), ("dt_control", C.c_double),
                 ("random_kick", C.c_double),
                 ("obs_nx", C.c_int32), ("obs_nz", C.c_int32),
-                ("batch", C.c_int32), ("device", C.c_int32), ("write_state", C.c_int32), ("precision", C.c_int32)]
+                ("batch", C.c_int32), ("device", C.c_int32), ("write_state", C.c_int32), ("precision", C.c_int32),
+                ("reference_clock", C.c_int32)]
 
 PRECISIONS = {"f64": 0, "f32": 1}
+# rbc_config.reference_clock (include/rbc_hip.h): "documented" = every env-step integrates heater_duration, what the reference's
+# sources say (rbc_sim2D_api.jl:84-85); "recorded" = what its recorded flowstats series show: the first env-step after a reset
+# carries all its solver steps, every later one of them one less
+CLOCKS = {"documented": 0, "recorded": 1}
+
+
+def clock_code(name):
+    if name in CLOCKS:
+        return CLOCKS[name]
+    if name in CLOCKS.values():
+        return int(name)
+    raise ValueError(f"reference_clock must be one of {sorted(CLOCKS)}, got {name!r}")
 
 
 # every symbol include/rbc_hip.h declares: name -> (restype, argtypes)
@@ -221,7 +234,7 @@ class NativeSim:
         for k, v in kw.items():
             if not hasattr(cfg, k):
                 raise TypeError(f"unknown config field {k}")
-            setattr(cfg, k, v)
+            setattr(cfg, k, clock_code(v) if k == "reference_clock" else v)
         self.cfg = cfg
         self.h = _vp()
         self._check(self.lib.rbc_create(C.byref(cfg), C.byref(self.h)))
@@ -377,10 +390,12 @@ class NativeSim3D:
     """A batch of B 3D envs on one GPU (rbc_sim3D_api.jl semantics; array shapes (nz, ny, nx))."""
 
     def __init__(self, batch=1, device=0, shape=(16, 32, 32), domain=(2.0, 4 * np.pi, 4 * np.pi), ra=2500.0, pr=0.7,
-                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01, random_kick=None, precision=0):
+                 t_diff=(1.0, 2.0), heaters=8, heater_limit=0.9, dt_control=0.125, dt_solver=0.01, random_kick=None, precision=0,
+                 reference_clock="documented"):
         self.lib = load_library()
         cfg = default_config()
         cfg.precision = int(PRECISIONS.get(precision, precision))
+        cfg.reference_clock = clock_code(reference_clock)
         nz, ny, nx = shape
         lz, ly, lx = domain
         cfg.dim, cfg.nx, cfg.ny, cfg.nz = 3, int(nx), int(ny), int(nz)

@@ -47,9 +47,11 @@ class RayleighBenardConvection3DEnv(NativeEnvBase):
         env_id: int = 0,
         device: int = 0,
         precision: str = "f64",          # "f64": the reference's Float64 arithmetic; "f32": the float32 instantiation of the 3D kernels
+        reference_clock: str = "documented",   # "recorded": the solver-step count of the reference's recorded series
     ) -> None:
         super().__init__()
         self.precision = precision
+        self.reference_clock = reference_clock
         self.ra, self.pr = rayleigh_number, prandtl_number
         self.domain, self.state_shape = domain, state_shape
         self.temperature_difference = temperature_difference
@@ -60,7 +62,8 @@ class RayleighBenardConvection3DEnv(NativeEnvBase):
         self.action_space, self.observation_space = build_spaces3d(state_shape, temperature_difference, heater_segments, heater_limit)
         sim = _native.NativeSim3D(batch=1, device=device, shape=tuple(state_shape), domain=tuple(domain), ra=float(rayleigh_number),
                                   pr=float(prandtl_number), t_diff=tuple(temperature_difference), heaters=heater_segments,
-                                  heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver, precision=precision)
+                                  heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver, precision=precision,
+                                  reference_clock=reference_clock)
         self._setup(sim, episode_length, checkpoint, render_mode, env_logger(__name__, log_dir, env_id))
 
     def _checked_action(self, action):

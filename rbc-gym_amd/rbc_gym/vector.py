@@ -127,7 +127,8 @@ class _BatchedEnv(gym.vector.VectorEnv):
 class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
     def __init__(self, num_envs=1, rayleigh_number=10_000, episode_length=300, observation_shape=(8, 48),
                  state_shape=(64, 96), heater_segments=12, heater_limit=0.75, heater_duration=1.5, pressure=False,
-                 use_gpu=True, checkpoint=None, render_mode=None, device=0, devices=None, info_state=True, precision="f64", **_ignored):
+                 use_gpu=True, checkpoint=None, render_mode=None, device=0, devices=None, info_state=True, precision="f64",
+                 reference_clock="documented", **_ignored):
         # info_state: True = info["state"] is a fresh array every step (the reference's behaviour), "pinned" = it rotates over
         # three page-locked buffers (3x faster device-to-host copy; an array is overwritten three steps later), False = omitted
         self.num_envs = int(num_envs)
@@ -147,6 +148,7 @@ class RayleighBenardConvection2DVectorEnv(_BatchedEnv):
         kw = sim_kwargs(ra0, self.observation_shape, self.state_shape, heater_segments, heater_limit, heater_duration)
         kw["precision"] = _native.PRECISIONS[precision]      # "f32": float32 arithmetic, envs paired up per workgroup
         self.precision = precision
+        kw["reference_clock"] = self.reference_clock = reference_clock     # "recorded": see _native.CLOCKS
         # devices=[0, 1, ...]: the envs are split into contiguous ranges, one library handle per GPU (rbc_gym/sharded.py)
         self.devices = None if devices is None else [int(d) for d in devices]
         if self.devices is None:
@@ -216,7 +218,7 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
     def __init__(self, num_envs=1, rayleigh_number=2500, prandtl_number=0.7, domain=(2, 4 * np.pi, 4 * np.pi),
                  state_shape=(16, 32, 32), temperature_difference=(1, 2), heater_segments=8, heater_limit=0.9,
                  heater_duration=0.125, episode_length=300, dt_solver=0.01, use_gpu=True, checkpoint=None, checkpoint_idx=None,
-                 render_mode=None, device=0, devices=None, precision="f64", obs_buffers=None, **_ignored):
+                 render_mode=None, device=0, devices=None, precision="f64", obs_buffers=None, reference_clock="documented", **_ignored):
         # obs_buffers: None = every reset / step returns a fresh observation array (the reference's behaviour); "pinned" = the
         # observations rotate over three page-locked buffers (an array stays valid for two more steps): the 38 MB of a
         # configs[4] batch cross PCIe at the pinned rate, 4.4k instead of 3.1k env-steps/s through the gym API
@@ -224,6 +226,7 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
         self.obs_buffers = obs_buffers
         self._pinned, self._pin_at = None, 0
         self.num_envs = int(num_envs)
+        self.reference_clock = reference_clock                       # "recorded": see _native.CLOCKS
         self.precision = precision                                   # "f32": the float32 instantiation of the 3D kernels (1.5x at configs[4])
         self.ra, self.pr = rayleigh_number, prandtl_number
         self.dim = 3
@@ -238,7 +241,8 @@ class RayleighBenardConvection3DVectorEnv(_BatchedEnv):
         def make(count, dev):
             return _native.NativeSim3D(batch=count, device=dev, shape=tuple(state_shape), domain=tuple(domain), ra=ra0,
                                        pr=float(prandtl_number), t_diff=tuple(temperature_difference), heaters=heater_segments,
-                                       heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver, precision=precision)
+                                       heater_limit=heater_limit, dt_control=heater_duration, dt_solver=dt_solver, precision=precision,
+                                       reference_clock=reference_clock)
         self.devices = None if devices is None else [int(d) for d in devices]
         self.sim = make(self.num_envs, device) if self.devices is None else ShardedSim(make, self.num_envs, self.devices)
         if np.ndim(rayleigh_number) > 0:

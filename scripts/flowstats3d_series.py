@@ -4,9 +4,10 @@ number in one batch: Nu(t), max|u|, max|v|, max|w| of the float32 state after ev
 experiments/flowstats/flowstats_ra.py:55-66 records), for the first STEPS steps.  Compared by tests/test_gpu_parity3d.py
 and scripts/flowstats3d_compare.py with the reference's own series (tests/golden/flowstats_ref_series.npz).
 
-    python scripts/flowstats3d_series.py [seeds=16] [steps=100] [out=gpurun_out/flowstats3d_series.npz] [dt_control=0.25] [dt_solver=0.005] [lead_substeps=0]
-Needs an MI355X.  RBC_EXPERIMENT_RK3 (see rbc3d_host.hpp) selects deliberately wrong RK3 coefficients for the
-"does the pin discriminate" experiment.
+    python scripts/flowstats3d_series.py [seeds=16] [steps=100] [out=gpurun_out/flowstats3d_series.npz] [dt_control=0.25] [dt_solver=0.005] [lead_substeps=0] [clock=documented|recorded]
+Needs an MI355X.  clock=recorded runs the product switch `reference_clock="recorded"` (rbc_config.reference_clock: all solver
+steps in the first env-step after a reset, one less in every later one).  A library built with -DRBC_EXPERIMENTS=1 reads
+RBC_EXPERIMENT_RK3 (rbc3d_host_body.hpp): deliberately wrong RK3 coefficients for the "does the pin discriminate" experiment.
 """
 import os
 import sys
@@ -24,13 +25,14 @@ def shape_tff(shape, lz=2.0):
     return lz * lz
 
 
-def run_series(ras, seeds, steps, seed0=777, shape=(32, 64, 64), dt_control=0.25, dt_solver=0.005, progress=None, lead_substeps=0):
+def run_series(ras, seeds, steps, seed0=777, shape=(32, 64, 64), dt_control=0.25, dt_solver=0.005, progress=None, lead_substeps=0,
+               reference_clock="documented"):
     """-> dict of arrays [len(ras), seeds, steps]: nusselt, umax, vmax, wmax (flowstats_ra.py:27-36 protocol, zero action)."""
     import torch
     from rbc_gym.vector import DeviceArray
     ras = np.asarray(ras, dtype=np.float64)
     R, B = len(ras), len(ras) * seeds
-    sim = _native.NativeSim3D(batch=B, shape=shape, dt_control=dt_control, dt_solver=dt_solver)
+    sim = _native.NativeSim3D(batch=B, shape=shape, dt_control=dt_control, dt_solver=dt_solver, reference_clock=reference_clock)
     sim.set_rayleigh(np.repeat(ras, seeds))                       # env index = ra_index * seeds + member
     sim.reset(np.arange(B, dtype=np.uint64) + np.uint64(seed0))
     nz, ny, nx = shape
@@ -60,8 +62,10 @@ if __name__ == "__main__":
     dt_control = float(sys.argv[4]) if len(sys.argv) > 4 else 0.25        # experiments only: the protocol's values are the defaults
     dt_solver = float(sys.argv[5]) if len(sys.argv) > 5 else 0.005
     lead = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    clock = sys.argv[7] if len(sys.argv) > 7 else "documented"
     ref = np.load(os.path.join(ROOT, "tests", "golden", "flowstats_ref_series.npz"))
-    out = run_series(ref["ra"], seeds, steps, dt_control=dt_control, dt_solver=dt_solver, progress=lambda s: print(s, flush=True), lead_substeps=lead)
+    out = run_series(ref["ra"], seeds, steps, dt_control=dt_control, dt_solver=dt_solver, progress=lambda s: print(s, flush=True), lead_substeps=lead,
+                     reference_clock=clock)
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     np.savez_compressed(dst, ra=ref["ra"], **out)
     for i, ra in enumerate(ref["ra"]):

@@ -439,7 +439,8 @@ def test_flowstats_series_pin(native, golden_dir):
     assert 0.976 < sn["slope_mean"] < 0.989 and sn["slope_sem"] < 0.003 and abs(sn["tau1_mean"] - 1.0) < 0.05, sn
     vel = np.mean([base[k]["slope_mean"] for k in ("umax", "vmax", "wmax")])
     assert 0.93 < vel < 1.01, base
-    out49 = run_series(ras, seeds, 30, seed0=4242, dt_control=0.245, lead_substeps=1)      # (e)
+    # (e) the PRODUCT switch reference_clock="recorded" (rbc_config.reference_clock; no test-side hook): over the growth window as before ...
+    out49 = run_series(ras, seeds, 30, seed0=4242, reference_clock="recorded")
     s49 = summary(analyse(ref, out49))["nusselt"]
     assert abs(s49["slope_mean"] - 1.0) < 0.008, s49
     def zscores(o):
@@ -455,7 +456,51 @@ def test_flowstats_series_pin(native, golden_dir):
     # maximum (recorded with 16 members: rms 1.02, all 240 below 2.6 -- against rms 1.84, 11 % beyond 3 for the documented clock)
     assert rms49 < 1.6 and (np.abs(z49) < 3).mean() > 0.96 and rms50 > 1.25 * rms49, (rms49, rms50)
     print(f"flowstats series pin: max |z| steps 1-3 = {worst:.2f}; build/theory increments {np.mean(ratios):.4f}; tau slope {sn['slope_mean']:.4f} "
-          f"+- {sn['slope_sem']:.4f}, tau(1) {sn['tau1_mean']:.3f}; velocity slopes {vel:.3f}; 50-then-49: slope {s49['slope_mean']:.4f}, rms z {rms49:.2f} (documented clock {rms50:.2f})")
+          f"+- {sn['slope_sem']:.4f}, tau(1) {sn['tau1_mean']:.3f}; velocity slopes {vel:.3f}; recorded clock: slope {s49['slope_mean']:.4f}, rms z {rms49:.2f} (documented clock {rms50:.2f})")
+
+
+def recorded_window_zscores(ref, out, steps):
+    """z of the reference's single realisation against the ensemble, all four series of flowstats_ra.py:55-66 on their
+    log-amplitudes, [series][ra][step]; members' spread inflated by sqrt(1 + 1/M) for the ensemble mean's own error"""
+    from flowstats3d_tau import SERIES, log_amplitude
+    z = {}
+    for name in SERIES:
+        M = out[name].shape[1]
+        la = log_amplitude(name, out[name][:, :, :steps])
+        z[name] = (log_amplitude(name, ref[name][:, :steps]) - la.mean(1)) / (la.std(1, ddof=1) * np.sqrt(1.0 + 1.0 / M))
+    return z
+
+
+def test_recorded_clock_reproduces_the_whole_recorded_window(native, golden_dir):
+    """`reference_clock="recorded"` against EVERYTHING the reference recorded with a time axis: 14 Rayleigh numbers x the first
+    60 env-steps x four series (Nu, max|u|, max|v|, max|w| of experiments/flowstats/flowstats_ra.pkl, flowstats_ra.py:55-66) --
+    decay of the kick, linear growth, overshoot, decay towards the statistically steady state.  16 members per Ra on the native 3D
+    stepper at the reference's protocol; the reference is one realisation, so z = (reference - ensemble mean) / member spread on
+    the log-amplitudes.  Bars: rms z over the whole window <= 1.3 per series (a t-distribution with 15 degrees of freedom has
+    rms 1.07), tau-slope of the Nusselt series 1.000 +- 0.005; the documented clock fails both (it is the default all the same:
+    it is what rbc_sim3D_api.jl:88-89 says)."""
+    import sys
+    for p in (os.path.join(os.path.dirname(golden_dir), "..", "scripts"), os.path.dirname(golden_dir)):
+        sys.path.insert(0, p)
+    from flowstats3d_series import run_series
+    from flowstats3d_tau import SERIES, analyse, summary
+    ref = np.load(os.path.join(golden_dir, "flowstats_ref_series.npz"))
+    ras, seeds, steps = ref["ra"], 16, 60
+    rec = run_series(ras, seeds, steps, seed0=9090, reference_clock="recorded")
+    doc = run_series(ras, seeds, steps, seed0=9090)
+    srec, sdoc = summary(analyse(ref, rec))["nusselt"], summary(analyse(ref, doc))["nusselt"]
+    zr, zd = recorded_window_zscores(ref, rec, steps), recorded_window_zscores(ref, doc, steps)
+    rms = lambda z: float(np.sqrt((z ** 2).mean()))
+    line = {k: (round(rms(zr[k]), 2), round(rms(zd[k]), 2)) for k in SERIES}
+    print(f"recorded clock, 14 Ra x {steps} steps, 16 members: rms z per series (recorded, documented) {line}; tau slope "
+          f"{srec['slope_mean']:.4f} +- {srec['slope_sem']:.4f} (documented {sdoc['slope_mean']:.4f}); worst |z| "
+          f"{max(float(np.abs(zr[k]).max()) for k in SERIES):.1f}")
+    assert abs(srec["slope_mean"] - 1.0) < 0.005 and abs(sdoc["slope_mean"] - 0.9825) < 0.006, (srec, sdoc)
+    for k in SERIES:
+        assert rms(zr[k]) <= 1.3, (k, line)
+    assert rms(zd["nusselt"]) > 1.3 * rms(zr["nusselt"]), line
+    all_r = np.concatenate([zr[k].ravel() for k in SERIES])
+    assert (np.abs(all_r) < 3).mean() > 0.98, float((np.abs(all_r) < 3).mean())
 
 
 def test_roundoff_sized_extra_substep_changes_nothing(native):

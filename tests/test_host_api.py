@@ -55,18 +55,37 @@ def test_default_config_is_the_registry_default(native):
     assert (c.nx, c.nz, c.obs_nx, c.obs_nz, c.heaters) == (96, 64, 48, 8, 12)
     assert c.ra == 1e4 and c.pr == 0.7 and c.heater_limit == 0.75 and c.dt_solver == 0.03 and c.dt_control == 1.5
     assert abs(c.lx - 2 * np.pi) < 1e-15 and c.lz == 2.0 and c.min_b == 1 and c.delta_b == 1 and c.random_kick == 0.01
+    assert c.reference_clock == native.CLOCKS["documented"] == 0         # the sources' clock is the default; "recorded" is opt-in
 
 
 def test_invalid_configs_are_rejected_before_touching_the_device(native):
     lib = native.load_library()
     for field, value, frag in (("dim", 4, "dim must be"), ("nx", 4, "unsupported 2D grid"), ("precision", 7, "precision"), ("batch", 0, "batch"),
-                               ("heaters", 0, "heaters"), ("obs_nx", 5, "sensor"), ("abi_version", 99, "abi_version")):
+                               ("heaters", 0, "heaters"), ("obs_nx", 5, "sensor"), ("abi_version", 99, "abi_version"),
+                               ("reference_clock", 2, "reference_clock")):
         cfg = native.default_config()
         setattr(cfg, field, value)
         h = C.c_void_p()
         rc = lib.rbc_create(C.byref(cfg), C.byref(h))
         assert rc == native.RBC_ERR_INVALID and not h.value
         assert frag in lib.rbc_last_error().decode()
+
+
+def test_recorded_clock_needs_more_than_one_solver_step(native):
+    """RBC_CLOCK_RECORDED drops one full solver step from every env-step but the first: refused where there is none to drop"""
+    lib = native.load_library()
+    cfg = native.default_config()
+    cfg.reference_clock, cfg.dt_control = native.CLOCKS["recorded"], cfg.dt_solver
+    h = C.c_void_p()
+    assert lib.rbc_create(C.byref(cfg), C.byref(h)) == native.RBC_ERR_INVALID and "dt_control > dt_solver" in lib.rbc_last_error().decode()
+    with pytest.raises(ValueError):
+        native.clock_code("julia")
+
+
+def test_shipped_library_has_no_experiment_knobs(native):
+    """numerics-changing RBC_EXPERIMENT_* environment knobs exist only in -DRBC_EXPERIMENTS=1 builds made by scripts/"""
+    blob = open(native.LIB_PATH, "rb").read()
+    assert b"RBC_EXPERIMENT" not in blob
 
 
 def test_no_gpu_means_failure_not_fallback(native):
