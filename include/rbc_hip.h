@@ -118,7 +118,8 @@ int  rbc_set_rayleigh(rbc_handle *h, const double *ra);
    the 2D step kernel: obs[c] = maxval * (2 * (obs[c] - min_vals[c]) / (max_vals[c] - min_vals[c]) - 1), evaluated
    in float32 in exactly that order on the float32-rounded sample, the python-float bounds rounded to float32 where
    numpy rounds them (bit-identical to the numpy wrapper), then
-   clipped to [-maxval, maxval] if clip != 0.  nch <= 5 channels (b,u,w,pHY',pNHS); channels >= nch stay raw;
+   clipped to [-maxval, maxval] if clip != 0 (a NaN stays a NaN, as with np.clip: a blown-up env is visible in its observation as
+   well as in rbc_get_flags).  nch <= 5 channels (b,u,w,pHY',pNHS); channels >= nch stay raw;
    nch = 0 switches the transform off.  Takes effect from the next reset/step; rbc_get_state is never transformed.
    dim=3: nch <= 4 channels (b,u,v,w).  The 3D observation IS the float32 state buffer (rbc3D.py:229-232), so there the
    transform applies to what rbc_get_obs / rbc_get_state / rbc_dev_state hand out (rewritten at once for the current state);

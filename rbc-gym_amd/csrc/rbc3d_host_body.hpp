@@ -297,8 +297,7 @@ inline rbc3_grp whole_batch(const rbc_handle *h) { return rbc3_grp{0, h->B, h->s
 
 // exact projection of state buffer `which` (0/1) of the group's envs with stage step dts (mask: device pointer [B] or null)
 // (want_phi = false: the caller does not need the potential itself afterwards -- only the one-kernel streaming-2D projection can skip its store)
-// (defer_w = true: leave  w -= dts dphi/dz  to the next stage's tile kernels -- see tile_correct_w; mirror-packed path only)
-int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask, bool want_phi = true, bool defer_w = false)
+int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uint8_t *mask, bool want_phi = true)
 {
     rbc3_state *s = S3(h);
     const K3::Geo3 &g = s->g;
@@ -338,7 +337,11 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
         else
         if (s->rows2d) hipLaunchKernelGGL(K3::k2s_ifft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
         else hipLaunchKernelGGL(K3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
-        if (!defer_w) hipLaunchKernelGGL(K3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
+#if RBC_EXPERIMENTS      /* timing bound only (WRONG numerics): what a stage costs without the separate vertical correction */
+        static const bool skip_cw = [] { const char *e = std::getenv("RBC_EXPERIMENT_SKIP_CW"); return e && e[0] == '1'; }();
+        if (!skip_cw)
+#endif
+        hipLaunchKernelGGL(K3::k3_correct_w, grid_for((size_t)B * (g.nc - pln), 256), dim3(256), 0, q.st, g, buf, phi, dts, B, mk);
 #undef RBC_IP_RHS
 #undef RBC_IP_INV
         HIP3(hipGetLastError());
@@ -438,17 +441,6 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             if (kt > 0 && g.nz % kt == 0) shape = kt == 64 ? 9 : (kt == 32 ? 8 : (kt == 16 ? 5 : (kt == 8 ? 6 : (kt == 4 ? 7 : shape))));
         }
     }
-    // RBC_DEFER_W=1: the vertical half of a stage's projection deferred into the next stage's tile kernels (tile_correct_w) instead
-    // of the separate k3_correct_w pass: one launch and 1.2 MB per env and stage less.  Parity-green in both precisions
-    // (tests/test_gpu_parity3d.py) and a measured LOSS in both (configs[4], three A/B repeats on one box): float64 4.84k against
-    // 5.95k env-steps/s (the two phi planes held across a level push the (w, b) body from 6 to 26 spilled VGPRs at the
-    // 168-register cap), float32 8.97k against 9.11k (no spill, but the extra loads and selects in the tile kernels cost more than
-    // the pass they replace).  Off by default; kept as a tested knob.
-    const bool can_defer = shape >= 1 && shape <= 4 && !h->stream2d && g.nz % 2 == 0 && !h->no_pair &&
-                           ([] { const char *e = std::getenv("RBC_DEFER_W"); return e && e[0] == '1'; }());
-    const real *phi_g = s->phi + (size_t)q.e0 * g.nc;
-    bool pending = false;                                      // cur holds w* of the previous stage, its phi / dts below
-    double dts_pending = 0.0;
     for (int n = 0; n < nsub; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;
         for (int ph = 0; ph < 3; ++ph) {
@@ -459,18 +451,17 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             else if (h->stream2d && n == nsub - 1 && ph >= 1)  // un-split tendencies: the two scans k2s_output needs to return pNHS
                 hipLaunchKernelGGL(K3::k3_hydrostatic, grid_for((size_t)B * g.nx * g.ny, 128), dim3(128), 0, q.st, g, cur,
                                    ph == 2 ? phy : s->phy2 + (size_t)q.e0 * g.nc, B);
-#undef RBC_TILE_NOPHI
-#if RBC_STAMPS            /* diagnostic build: the unused phi argument carries the stamp buffer (TSTAMP in rbc3d_kernels_body.hpp) */
-#define RBC_TILE_NOPHI reinterpret_cast<const real *>(h->d_stamps)
+#undef RBC_TILE_STAMPS
+#if RBC_STAMPS            /* diagnostic build: the last argument carries the stamp buffer (TSTAMP in rbc3d_kernels_body.hpp) */
+#define RBC_TILE_STAMPS reinterpret_cast<const real *>(h->d_stamps)
 #else
-#define RBC_TILE_NOPHI (const real *)nullptr
+#define RBC_TILE_STAMPS (const real *)nullptr
 #endif
 #define RBC_TILE_LAUNCH(TY, KT, THR, WAVES)                                                                                              \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * K3::NXP3 * sizeof(real);                                                        \
-                if (pending) hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, 0, 0, true>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, phi_g, dts_pending); \
-                else hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_NOPHI, 0.0); \
+                hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_STAMPS); \
             }
             // (48, 48) horizontal planes -- configs[4] --, the registry default (32, 32) and the flowstats experiment's (64, 64) have
             // instantiations with nx, ny as compile-time constants: the index arithmetic of the plane staging becomes multiplications
@@ -479,8 +470,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.ny / TY) * (g.nz / KT))), bt(g.nx * TY);                                      \
                 const size_t pb = (size_t)(TY + 6) * K3::NXP3 * sizeof(real);                                                        \
-                if (pending) hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, NXC_, NYC_, true>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, phi_g, dts_pending); \
-                else hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_NOPHI, 0.0); \
+                hipLaunchKernelGGL((K3::k3_tile_all<TY, KT, 2, THR, WAVES, K3::NXP3, false, NXC_, NYC_>), gt, bt, 3 * pb, q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_STAMPS); \
             }
             const bool c48 = (g.nx == 48 && g.ny == 48 && !no_nxc), c32 = (g.nx == 32 && g.ny == 32 && !no_nxc), c64 = (g.nx == 64 && g.ny == 64 && !no_nxc);
             if (shape == 1 && c48) RBC_TILE_LAUNCHC(16, 16, 768, TW3, 48, 48)
@@ -499,7 +489,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
 #define RBC_FLAT_LAUNCH(KT)                                                                                                              \
             {                                                                                                                            \
                 const dim3 gt((unsigned)(2 * (size_t)B * (g.nz / KT))), bt(g.nx);                                                         \
-                hipLaunchKernelGGL((K3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(real), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_NOPHI, 0.0); \
+                hipLaunchKernelGGL((K3::k3_tile_all<1, KT, 1, 256, 3, 256, true>), gt, bt, 3 * 256 * sizeof(real), q.st, g, cur, nxt, gm, actT, ra, d, gam[ph], zet[ph], store_g, RBC_TILE_STAMPS); \
             }
             else if (shape == 5) RBC_FLAT_LAUNCH(16)
             else if (shape == 6) RBC_FLAT_LAUNCH(8)
@@ -525,8 +515,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             // its own projection (outputs and the next env-step read the projected state)
             const bool last = (n == nsub - 1 && ph == 2);
             const double dts = (gam[ph] + zet[ph]) * d;
-            if (int rc = project3d(h, q, which ^ 1, dts, nullptr, last, can_defer && !last)) return rc;
-            pending = can_defer && !last; dts_pending = dts;
+            if (int rc = project3d(h, q, which ^ 1, dts, nullptr, last)) return rc;
             which ^= 1;
         }
     }

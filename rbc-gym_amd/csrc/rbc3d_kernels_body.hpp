@@ -418,8 +418,49 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const real *cur, re
 // are never read again (zeta^1 = 0).
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
 
+// One env's [b | u | v | w] block of a state-sized buffer (state, next state or G^-) as the tile kernels address it: a UNIFORM
+// element offset (field + level, computed on the scalar unit) plus a 32-bit per-lane BYTE offset (own column, or the plane element
+// a thread stages).  BUF = false (shipped): plain pointer arithmetic; hipcc folds `base + column` into a 64-bit VGPR pair and spends
+// one v_lshl_add_u64 per access on the uniform part (99 of them in the configs[4] tile kernel: a third of its non-fp64 VALU
+// instructions).  BUF = true (-DRBC_TILE_BUFFER_ADDR=1): through a buffer descriptor that covers exactly this env's
+// block -- `buffer_load_dwordx2 v, v_off, s[rsrc:rsrc+3], s_off offen`, NO vector instruction per access: 1 v_lshl_add_u64 left in
+// the kernel, 166 -> 141 VGPRs (float32: 130 -> 100).  Measured on one box, three interleaved repeats (scripts/ab_rate3d.sh,
+// configs[4]): float64 6.32k against 6.36k env-steps/s (noise), float32 9.16k against 9.48k (-3.4 %).  The address arithmetic was
+// never what the kernel waits for (it is bound by operand latency and the two barriers of a level); the
+// descriptor path is kept as a build flag for the record, off.
+#ifndef RBC_TILE_BUFFER_ADDR
+#define RBC_TILE_BUFFER_ADDR 0
+#endif
+__device__ __forceinline__ void buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff, double &x) { x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+__device__ __forceinline__ void buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff, float &x) { x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)), x), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int voff, int soff, float x) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, voff, soff, 0); }
+
+template <bool BUF>
+struct EnvMem {
+    real *p;
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ EnvMem(const real *base, size_t elems) : p(const_cast<real *>(base))
+    {
+        if constexpr (BUF) r = __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(elems * sizeof(real)), 0x00020000);
+    }
+    __device__ __forceinline__ real ld(size_t off, unsigned boff) const
+    {
+        if constexpr (BUF) { real x; buf_ld(r, (int)boff, (int)(off * sizeof(real)), x); return x; }
+        else return *reinterpret_cast<const real *>(reinterpret_cast<const char *>(p + off) + boff);
+    }
+    __device__ __forceinline__ void st(size_t off, unsigned boff, real x) const
+    {
+        if constexpr (BUF) buf_st(r, (int)boff, (int)(off * sizeof(real)), x);
+        else *reinterpret_cast<real *>(reinterpret_cast<char *>(p + off) + boff) = x;
+    }
+};
+
 // Diagnostic build only (-DRBC_STAMPS=1, never shipped; scripts/tile_stamps.py): wave 0 of every tile workgroup accumulates
-// s_memtime ticks per phase of its level loop and adds them to stamps[16 * body + id] (the `phi` argument carries the buffer).
+// s_memtime ticks per phase of its level loop and adds them to stamps[16 * body + id] (the kernel's last argument carries the buffer, null in the shipped build).
 #undef TSTAMP
 #undef TSTAMP_INIT
 #undef TSTAMP_FLUSH
@@ -474,11 +515,14 @@ struct TileGeo {
     }
 };
 
-template <int NPF, class TG>
-__device__ __forceinline__ void tile_fetch(const TG &t, const real *lev, real (&pf)[NPF])
+template <int NPF, class TG, class MEM>
+__device__ __forceinline__ void tile_fetch(const TG &t, const MEM &m, size_t lev, real (&pf)[NPF])
 {
 #pragma unroll
-    for (int q = 0; q < NPF; ++q) { const int idx = t.tid + q * t.nthreads; pf[q] = (idx < t.plane) ? lev[t.src(idx)] : real(0.0); }
+    for (int q = 0; q < NPF; ++q) {
+        const int idx = t.tid + q * t.nthreads;
+        pf[q] = (idx < t.plane) ? m.ld(lev, (unsigned)t.src(idx) * (unsigned)sizeof(real)) : real(0.0);
+    }
 }
 template <int NPF, class TG>
 __device__ __forceinline__ void tile_store(const TG &t, real *dst, const real (&pf)[NPF])
@@ -493,27 +537,13 @@ __device__ __forceinline__ void tile_store(const TG &t, real *dst, const real (&
     }
 }
 
-// Deferred vertical half of the previous stage's projection (DEFW = true): the inverse-FFT kernel has corrected u and v
-// (it holds phi of its slab in LDS), but  w -= dts dphi/dz  needs phi of the slab below and used to be a pass of its own
-// (k3_correct_w: read w, read phi twice, write w, one more launch per stage).  Instead the state buffer keeps w* and the
-// tendency kernels of the NEXT stage apply the correction to every w value as they load it -- planes while they are staged,
-// own-column window values as they are fetched: w(kf) -= (phi(kf) - phi(kf-1)) * rdz * dts on the interior faces 1..nz-1 (the
-// same expression and operation order as k3_correct_w).  Only the last stage of an env-step still runs k3_correct_w, so that
-// outputs and the next env-step see the projected state.
-template <int NPF>
-__device__ __forceinline__ void tile_correct_w(real (&wv)[NPF], const real (&pn)[NPF], const real (&pp)[NPF], real rdz, real dts)
-{
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) wv[q] -= (pn[q] - pp[q]) * rdz * dts;
-}
-
 // (u, v): blockDim = nx * TY3, B * (ny/TY3) * (nz/KT3) workgroups, LDS = 3 planes.  Two shapes are built:
 // 16 rows x 4 levels (768 threads = 12 waves, three per SIMD, register budget 168) where ny % 16 == 0, else 8 x 8
 // (up to 512 threads, budget 256); the first is 3 % faster at 48 x 48 x 32 (smaller halo share, even SIMD load).
-template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0, bool DEFW = false>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, real *nxt, real *gm,
                                              const f64 *nu_kappa, real dt, real gam, real zet, int store_g, int blk,
-                                             const real *phi = nullptr, real dts_prev = real(0.0))
+                                             const real *stamps = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) real tile_sm[];
     const TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC> t(g, blk);
@@ -521,8 +551,9 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     real *PU = tile_sm, *PV = tile_sm + PLANE3, *PW = tile_sm + 2 * PLANE3;        // u(k), v(k), w(k+1)
     constexpr int IU = 0, IV = PLANE3, IW = 2 * PLANE3;
-    const real *sb = cur + (size_t)t.env * g.env_stride;
-    const real *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const size_t eb = (size_t)t.env * g.env_stride;
+    const EnvMem<(!FLAT && RBC_TILE_BUFFER_ADDR)> S(cur + eb, g.env_stride), N(nxt + eb, g.env_stride), G(gm + eb, g.env_stride);      // state, next state, G^- of this env
+    const size_t u = g.nc, v = 2 * (size_t)g.nc, w = 3 * (size_t)g.nc;      // element offsets of the fields inside an env's block
     const real nu = nu_kappa[2 * t.env];
     const real rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
     int xi[7];
@@ -535,36 +566,24 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
     auto L = [&](int P, int a, int b) -> real { return xb[a + 3][P + (FLAT ? 0 : b * NXP)]; };
     auto ghost_lo = [&](real c1, real bc) -> real { return c1 + ((c1 - bc) / hz) * (-dz); };
     auto ghost_hi = [&](real cN, real bc) -> real { return cN + ((bc - cN) / hz) * dz; };
-    auto own = [&](const real *f, int kk) -> real { return f[(size_t)min(max(kk, 0), nz - 1) * pl + col]; };
+    const unsigned colb = (unsigned)col * (unsigned)sizeof(real);       // byte offset of the own column inside a level
+    auto own = [&](size_t f, int kk) -> real { return S.ld(f + (size_t)min(max(kk, 0), nz - 1) * pl, colb); };
 
     // stage level k0 (u, v) and k0+1 (w; level k0 itself is only needed for the chunk's bottom face, read below).  Every
     // global load of the prologue is issued here, before the first barrier, so that the workgroup waits for memory once
     // instead of once per barrier (a workgroup lives for four levels: an exposed round trip is a tenth of its life).
-    const size_t eb = (size_t)t.env * g.env_stride;
     const bool use_gm = (zet != real(0.0));                             // stage 1 never reads G^- (see k3_tendency)
     real pfu[NPF], pfv[NPF], pfw[NPF], pfw1[NPF];
-    tile_fetch(t, u + (size_t)t.k0 * pl, pfu);
-    if constexpr (!FLAT) tile_fetch(t, v + (size_t)t.k0 * pl, pfv);
-    tile_fetch(t, w + (size_t)t.k0 * pl, pfw);
-    tile_fetch(t, w + (size_t)min(t.k0 + 1, nz) * pl, pfw1);
-    // DEFW: phi planes k0-1, k0, k0+1 for the two w planes of the prologue; pfp then holds phi of the last staged face level
-    const real *ph = DEFW ? phi + (size_t)t.env * g.nc : nullptr;
-    real pfp[NPF], pfq[NPF], pfn[NPF];
-    if constexpr (DEFW) {
-        tile_fetch(t, ph + (size_t)max(t.k0 - 1, 0) * pl, pfq);
-        tile_fetch(t, ph + (size_t)t.k0 * pl, pfn);
-        tile_fetch(t, ph + (size_t)min(t.k0 + 1, nz - 1) * pl, pfp);
-    }
+    tile_fetch(t, S, u + (size_t)t.k0 * pl, pfu);
+    if constexpr (!FLAT) tile_fetch(t, S, v + (size_t)t.k0 * pl, pfv);
+    tile_fetch(t, S, w + (size_t)t.k0 * pl, pfw);
+    tile_fetch(t, S, w + (size_t)min(t.k0 + 1, nz) * pl, pfw1);
     real winu[6], winv[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) { winu[q] = own(u, t.k0 - 3 + q); winv[q] = FLAT ? real(0.0) : own(v, t.k0 - 3 + q); }
     // per-level global operands of this thread travel one level ahead of their use, like the planes
     real nu5 = own(u, t.k0 + 3), nv5 = FLAT ? real(0.0) : own(v, t.k0 + 3);
-    real ngu = use_gm ? gm[eb + g.nc + (size_t)t.k0 * pl + col] : real(0.0), ngv = (use_gm && !FLAT) ? gm[eb + 2 * (size_t)g.nc + (size_t)t.k0 * pl + col] : real(0.0);
-    if constexpr (DEFW) {
-        if (t.k0 > 0) tile_correct_w(pfw, pfn, pfq, rdz, dts_prev);           // face k0 (the wall face 0 carries no correction)
-        if (t.k0 + 1 < nz) tile_correct_w(pfw1, pfp, pfn, rdz, dts_prev);     // face k0 + 1
-    }
+    real ngu = use_gm ? G.ld(u + (size_t)t.k0 * pl, colb) : real(0.0), ngv = (use_gm && !FLAT) ? G.ld(v + (size_t)t.k0 * pl, colb) : real(0.0);
     tile_store(t, PW, pfw);                                       // w(k0) first: bottom-face terms of the chunk
     __syncthreads();
     real fbu = real(0.0), dwbu = real(0.0), fdnu, fbv = real(0.0), dwbv = real(0.0), fdnv;
@@ -594,13 +613,12 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
         winu[5] = nu5; winv[5] = nv5;
         const real gpu_ = ngu, gpv_ = ngv;
         if (more) {                                               // next level's planes and operands fly under this level's arithmetic
-            tile_fetch(t, u + (size_t)(k + 1) * pl, pfu);
-            if constexpr (!FLAT) tile_fetch(t, v + (size_t)(k + 1) * pl, pfv);
-            tile_fetch(t, w + (size_t)min(k + 2, nz) * pl, pfw);
-            if constexpr (DEFW) tile_fetch(t, ph + (size_t)min(k + 2, nz - 1) * pl, pfn);
+            tile_fetch(t, S, u + (size_t)(k + 1) * pl, pfu);
+            if constexpr (!FLAT) tile_fetch(t, S, v + (size_t)(k + 1) * pl, pfv);
+            tile_fetch(t, S, w + (size_t)min(k + 2, nz) * pl, pfw);
             nu5 = own(u, k + 4);
             if constexpr (!FLAT) nv5 = own(v, k + 4);
-            if (use_gm) { ngu = gm[eb + g.nc + (size_t)(k + 1) * pl + col]; if constexpr (!FLAT) ngv = gm[eb + 2 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; }
+            if (use_gm) { ngu = G.ld(u + (size_t)(k + 1) * pl, colb); if constexpr (!FLAT) ngv = G.ld(v + (size_t)(k + 1) * pl, colb); }
         }
         const bool top = (k + 1 >= nz);
         const real wc = top ? real(0.0) : L(IW, 0, 0);
@@ -630,10 +648,10 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             const real vis = nu * (real(2.0) * ((q7[4] - f0) - (f0 - q7[2])) * rdx * rdx
                                      + (((c7[4] - f0) * rdy + (on_c - on_m) * rdx) - ((f0 - c7[2]) * rdy + (os_c - os_m) * rdx)) * rdy
                                      + (((fup - f0) * rdz + dwt * rdx) - ((f0 - fdnu) * rdz + dwbu * rdx)) * rdz);
-            const real G = vis - adv;                          // buoyancy sits in G_w (see the header comment of these kernels)
-            const size_t o = eb + g.nc + (size_t)k * pl + col;
-            nxt[o] = f0 + dt * (gam * G + zet * gpu_);
-            if (store_g) gm[o] = G;
+            const real Gn = vis - adv;                         // buoyancy sits in G_w (see the header comment of these kernels)
+            const size_t o = u + (size_t)k * pl;
+            N.st(o, colb, f0 + dt * (gam * Gn + zet * gpu_));
+            if (store_g) G.st(o, colb, Gn);
             fbu = ft; dwbu = dwt; fdnu = f0;
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the two sections' live ranges apart
@@ -659,19 +677,14 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             const real vis = nu * (real(2.0) * ((q7[4] - f0) - (f0 - q7[2])) * rdy * rdy
                                      + (((c7[4] - f0) * rdx + (on_c - on_m) * rdy) - ((f0 - c7[2]) * rdx + (os_c - os_m) * rdy)) * rdx
                                      + (((fup - f0) * rdz + dwt * rdy) - ((f0 - fdnv) * rdz + dwbv * rdy)) * rdz);
-            const real G = vis - adv;
-            const size_t o = eb + 2 * (size_t)g.nc + (size_t)k * pl + col;
-            nxt[o] = f0 + dt * (gam * G + zet * gpv_);
-            if (store_g) gm[o] = G;
+            const real Gn = vis - adv;
+            const size_t o = v + (size_t)k * pl;
+            N.st(o, colb, f0 + dt * (gam * Gn + zet * gpv_));
+            if (store_g) G.st(o, colb, Gn);
             fbv = ft; dwbv = dwt; fdnv = f0;
         }
         TSTAMP(2);
         if (more) {
-            if constexpr (DEFW) {
-                if (k + 2 < nz) tile_correct_w(pfw, pfn, pfp, rdz, dts_prev);
-#pragma unroll
-                for (int q = 0; q < NPF; ++q) pfp[q] = pfn[q];
-            }
             __syncthreads();                                      // every read of this level's planes is done
             TSTAMP(3);
             tile_store(t, PU, pfu);
@@ -682,14 +695,14 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
             TSTAMP(5);
         }
     }
-    if constexpr (!DEFW) TSTAMP_FLUSH(0, phi);
+    TSTAMP_FLUSH(0, stamps);
 }
 
 // (w, b): same shape, LDS = 2 planes (w and b at the current level)
-template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0, bool DEFW = false>
+template <int TY3, int KT3, int NPF, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, real *nxt, real *gm, const f64 *actT,
                                              const f64 *nu_kappa, real dt, real gam, real zet, int store_g, int blk,
-                                             const real *phi = nullptr, real dts_prev = real(0.0))
+                                             const real *stamps = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) real tile_sm[];
     const TileGeo<TY3, KT3, NXP, FLAT, NXC, NYC> t(g, blk);
@@ -697,8 +710,9 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
     const int nx = t.nx, nz = t.nz, pl = t.pl;
     real *PW = tile_sm, *PB = tile_sm + PLANE3;
     constexpr int IW = 0, IB = PLANE3;
-    const real *sb = cur + (size_t)t.env * g.env_stride;
-    const real *b = sb, *u = sb + g.nc, *v = sb + 2 * (size_t)g.nc, *w = sb + 3 * (size_t)g.nc;
+    const size_t eb = (size_t)t.env * g.env_stride;
+    const EnvMem<(!FLAT && RBC_TILE_BUFFER_ADDR)> S(cur + eb, g.env_stride), N(nxt + eb, g.env_stride), G(gm + eb, g.env_stride);      // state, next state, G^- of this env
+    const size_t b = 0, u = g.nc, v = 2 * (size_t)g.nc, w = 3 * (size_t)g.nc;      // element offsets of the fields inside an env's block
     const real nu = nu_kappa[2 * t.env], ka = nu_kappa[2 * t.env + 1];
     const real rdx = g.rdx, rdy = g.rdy, rdz = g.rdz, dz = g.dz, hz = dz / 2;
     int xi[7];
@@ -712,46 +726,32 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
     auto L = [&](int P, int a, int bb) -> real { return xb[a + 3][P + (FLAT ? 0 : bb * NXP)]; };
     auto ghost_lo = [&](real c1, real bc) -> real { return c1 + ((c1 - bc) / hz) * (-dz); };
     auto ghost_hi = [&](real cN, real bc) -> real { return cN + ((bc - cN) / hz) * dz; };
-    auto cen = [&](const real *f, int c, int kk) -> real { return f[(size_t)min(max(kk, 0), nz - 1) * pl + c]; };
-    const real *ph = DEFW ? phi + (size_t)t.env * g.nc : nullptr;
-    auto fac = [&](int kk) -> real {                            // own-column w face; DEFW: with the deferred correction applied
-        const int kc = min(max(kk, 0), nz);
-        const real wv = w[(size_t)kc * pl + col];
-        if constexpr (DEFW) {
-            const int kp = min(max(kc, 1), nz - 1);               // clamped so that the loads stay inside phi; unused at the walls
-            const real pn = ph[(size_t)kp * pl + col], pp = ph[(size_t)(kp - 1) * pl + col];
-            return (kc >= 1 && kc <= nz - 1) ? wv - (pn - pp) * rdz * dts_prev : wv;
-        } else return wv;
-    };
+    // byte offsets of the own column and of its east / north neighbours inside a level (see EnvMem)
+    const unsigned colb = (unsigned)col * (unsigned)sizeof(real), colEb = (unsigned)colE * (unsigned)sizeof(real), colNb = (unsigned)colN * (unsigned)sizeof(real);
+    auto cen = [&](size_t f, unsigned cb, int kk) -> real { return S.ld(f + (size_t)min(max(kk, 0), nz - 1) * pl, cb); };
+    auto fac = [&](int kk) -> real { return S.ld(w + (size_t)min(max(kk, 0), nz) * pl, colb); };      // own-column w face
 
     // every global load of the prologue before the first barrier (see k3_tile_uv)
-    const size_t eb = (size_t)t.env * g.env_stride;
     const bool use_gm = (zet != real(0.0));                             // stage 1 never reads G^- (see k3_tendency)
     real pfw[NPF], pfb[NPF];
-    tile_fetch(t, w + (size_t)t.k0 * pl, pfw); tile_fetch(t, b + (size_t)t.k0 * pl, pfb);
-    real pfp[NPF], pfn[NPF];                                    // DEFW: phi planes of the last / the next staged w level
-    if constexpr (DEFW) {
-        tile_fetch(t, ph + (size_t)max(t.k0 - 1, 0) * pl, pfn);
-        tile_fetch(t, ph + (size_t)t.k0 * pl, pfp);
-    }
+    tile_fetch(t, S, w + (size_t)t.k0 * pl, pfw); tile_fetch(t, S, b + (size_t)t.k0 * pl, pfb);
     // z windows: w faces and b centres six deep (5-point stencils), the advecting u, v columns four deep (levels k-2..k+1: all the
     // centred interpolation to the w face reads)
     real winw[6], winb[6], au[4], eu[4], av[4], ev[4];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { winw[q] = fac(t.k0 - 3 + q); winb[q] = cen(b, col, t.k0 - 3 + q); }
+    for (int q = 0; q < 6; ++q) { winw[q] = fac(t.k0 - 3 + q); winb[q] = cen(b, colb, t.k0 - 3 + q); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        au[q] = cen(u, col, t.k0 - 3 + q); eu[q] = cen(u, colE, t.k0 - 3 + q);
-        av[q] = FLAT ? real(0.0) : cen(v, col, t.k0 - 3 + q); ev[q] = FLAT ? real(0.0) : cen(v, colN, t.k0 - 3 + q);
+        au[q] = cen(u, colb, t.k0 - 3 + q); eu[q] = cen(u, colEb, t.k0 - 3 + q);
+        av[q] = FLAT ? real(0.0) : cen(v, colb, t.k0 - 3 + q); ev[q] = FLAT ? real(0.0) : cen(v, colNb, t.k0 - 3 + q);
     }
     // per-level global operands of this thread travel one level ahead of their use, like the planes
-    real nw5 = fac(t.k0 + 3), nb5 = cen(b, col, t.k0 + 3);
-    real nau = cen(u, col, t.k0 + 1), neu = cen(u, colE, t.k0 + 1), nav = FLAT ? real(0.0) : cen(v, col, t.k0 + 1), nev = FLAT ? real(0.0) : cen(v, colN, t.k0 + 1);
-    real ngw = use_gm ? gm[eb + 3 * (size_t)g.nc + (size_t)t.k0 * pl + col] : real(0.0), ngb = use_gm ? gm[eb + (size_t)t.k0 * pl + col] : real(0.0);
+    real nw5 = fac(t.k0 + 3), nb5 = cen(b, colb, t.k0 + 3);
+    real nau = cen(u, colb, t.k0 + 1), neu = cen(u, colEb, t.k0 + 1), nav = FLAT ? real(0.0) : cen(v, colb, t.k0 + 1), nev = FLAT ? real(0.0) : cen(v, colNb, t.k0 + 1);
+    real ngw = use_gm ? G.ld(w + (size_t)t.k0 * pl, colb) : real(0.0), ngb = use_gm ? G.ld(b + (size_t)t.k0 * pl, colb) : real(0.0);
     real fbw = (t.k0 > 0) ? upw(zcS(winw, t.k0 - 1, nz), zcL(winw, t.k0 - 1, nz), zcR(winw, t.k0 - 1, nz)) : real(0.0);
     real fbb = (t.k0 > 0) ? upw(winw[3], zfL(winb, t.k0, nz), zfR(winb, t.k0, nz)) : real(0.0);
     real bdn = (t.k0 > 0) ? winb[2] : ghost_lo(winb[3], bottom_T(g, actT + (size_t)t.env * wall_stride(g), t.i, t.j));
-    if constexpr (DEFW) { if (t.k0 > 0) tile_correct_w(pfw, pfp, pfn, rdz, dts_prev); }
     tile_store(t, PW, pfw); tile_store(t, PB, pfb);
     __syncthreads();
 
@@ -767,12 +767,11 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
         au[3] = nau; eu[3] = neu; av[3] = nav; ev[3] = nev;       // u, v levels k-2..k+1
         const real gpw_ = ngw, gpb_ = ngb;
         if (more) {
-            tile_fetch(t, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, b + (size_t)(k + 1) * pl, pfb);
-            if constexpr (DEFW) tile_fetch(t, ph + (size_t)(k + 1) * pl, pfn);       // k + 1 <= nz - 1 here
-            nw5 = fac(k + 4); nb5 = cen(b, col, k + 4);
-            nau = cen(u, col, k + 2); neu = cen(u, colE, k + 2);
-            if constexpr (!FLAT) { nav = cen(v, col, k + 2); nev = cen(v, colN, k + 2); }
-            if (use_gm) { ngw = gm[eb + 3 * (size_t)g.nc + (size_t)(k + 1) * pl + col]; ngb = gm[eb + (size_t)(k + 1) * pl + col]; }
+            tile_fetch(t, S, w + (size_t)(k + 1) * pl, pfw); tile_fetch(t, S, b + (size_t)(k + 1) * pl, pfb);
+            nw5 = fac(k + 4); nb5 = cen(b, colb, k + 4);
+            nau = cen(u, colb, k + 2); neu = cen(u, colEb, k + 2);
+            if constexpr (!FLAT) { nav = cen(v, colb, k + 2); nev = cen(v, colNb, k + 2); }
+            if (use_gm) { ngw = G.ld(w + (size_t)(k + 1) * pl, colb); ngb = G.ld(b + (size_t)(k + 1) * pl, colb); }
         }
         __builtin_amdgcn_sched_barrier(0);
         TSTAMP(0);
@@ -780,7 +779,7 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
         {
             const real w0 = winw[2];
             const real ft = upw(zcS(winw, k, nz), zcL(winw, k, nz), zcR(winw, k, nz));
-            const size_t o = eb + 3 * (size_t)g.nc + (size_t)k * pl + col;
+            const size_t o = w + (size_t)k * pl;
             if (k > 0) {
                 real q7[7], c7[7];
 #pragma unroll
@@ -796,10 +795,10 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
                 const real vis = nu * ((((eu[2] - eu[1]) * rdz + (q7[4] - w0) * rdx) - ((au[2] - au[1]) * rdz + (w0 - q7[2]) * rdx)) * rdx
                                          + (((ev[2] - ev[1]) * rdz + (c7[4] - w0) * rdy) - ((av[2] - av[1]) * rdz + (w0 - c7[2]) * rdy)) * rdy
                                          + real(2.0) * ((winw[3] - w0) - (w0 - winw[1])) * rdz * rdz);
-                const real G = vis - adv + real(0.5) * (winb[1] + winb[2]);      // + b at the face: the un-split buoyancy term
-                nxt[o] = w0 + dt * (gam * G + zet * gpw_);
-                if (store_g) gm[o] = G;
-            } else { nxt[o] = real(0.0); if (store_g) gm[o] = real(0.0); }
+                const real Gn = vis - adv + real(0.5) * (winb[1] + winb[2]);     // + b at the face: the un-split buoyancy term
+                N.st(o, colb, w0 + dt * (gam * Gn + zet * gpw_));
+                if (store_g) G.st(o, colb, Gn);
+            } else { N.st(o, colb, real(0.0)); if (store_g) G.st(o, colb, real(0.0)); }
             fbw = ft;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -823,19 +822,14 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
             const real adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbb) * rdz;
             const real dif = ka * (((q7[4] - b0) - (b0 - q7[2])) * rdx * rdx + ((c7[4] - b0) - (b0 - c7[2])) * rdy * rdy
                                      + ((bup - b0) - (b0 - bdn)) * rdz * rdz);
-            const real G = dif - adv;
-            const size_t o = eb + (size_t)k * pl + col;
-            nxt[o] = b0 + dt * (gam * G + zet * gpb_);
-            if (store_g) gm[o] = G;
+            const real Gn = dif - adv;
+            const size_t o = b + (size_t)k * pl;
+            N.st(o, colb, b0 + dt * (gam * Gn + zet * gpb_));
+            if (store_g) G.st(o, colb, Gn);
             fbb = ft; bdn = b0;
         }
         TSTAMP(2);
         if (more) {
-            if constexpr (DEFW) {
-                tile_correct_w(pfw, pfn, pfp, rdz, dts_prev);
-#pragma unroll
-                for (int q = 0; q < NPF; ++q) pfp[q] = pfn[q];
-            }
             __syncthreads();
             TSTAMP(3);
             tile_store(t, PW, pfw); tile_store(t, PB, pfb);
@@ -844,22 +838,22 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
             TSTAMP(5);
         }
     }
-    if constexpr (!DEFW) TSTAMP_FLUSH(1, phi);
-    if (t.k0 + KT3 == nz) nxt[eb + 3 * (size_t)g.nc + (size_t)nz * pl + col] = real(0.0);      // top wall face
+    TSTAMP_FLUSH(1, stamps);
+    if (t.k0 + KT3 == nz) N.st(w + (size_t)nz * pl, colb, real(0.0));      // top wall face
 }
 
 // Both tendency kernels as ONE launch: the first half of the grid runs the (u, v) body, the second half the (w, b) body (they
 // read the same state buffer and write disjoint fields).  A kernel boundary on the dependent stream costs about 10 us on this
 // path whatever the kernels do (2.5 ms per env-step at B = 1, where all 234 launches are nearly empty); one launch fewer per
 // stage is worth more here than anything done inside the kernels.
-template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0, bool DEFW = false>
+template <int TY3, int KT3, int NPF, int MAXT, int WAVES, int NXP = NXP3, bool FLAT = false, int NXC = 0, int NYC = 0>
 __global__ void __launch_bounds__(MAXT, WAVES) k3_tile_all(Geo3 g, const real *cur, real *nxt, real *gm, const f64 *actT,
                                                    const f64 *nu_kappa, real dt, real gam, real zet, int store_g,
-                                                   const real *phi, real dts_prev)
+                                                   const real *stamps)
 {
     const int half = gridDim.x >> 1;                 // first half of the grid: (u, v); second half: (w, b), starting as the first drains
-    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC, DEFW>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half, phi, dts_prev);
-    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC, DEFW>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x, phi, dts_prev);
+    if ((int)blockIdx.x >= half) tile_wb_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC>(g, cur, nxt, gm, actT, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x - half, stamps);
+    else tile_uv_body<TY3, KT3, NPF, NXP, FLAT, NXC, NYC>(g, cur, nxt, gm, nu_kappa, dt, gam, zet, store_g, (int)blockIdx.x, stamps);
 }
 
 // ---- generic two-factor DFT of every line of a slab held in LDS ------------------------------------

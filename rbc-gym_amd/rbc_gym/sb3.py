@@ -38,9 +38,10 @@ def make_sb3_vec_env(env_id, n_envs, normalize=None, **env_kwargs):
 
     class RBCVecEnv(VecEnv):
         def __init__(self):
-            super().__init__(n_envs, venv.single_observation_space, venv.single_action_space)
+            # set before the base constructor runs: SB3 2.x's VecEnv.__init__ calls self.get_attr("render_mode"), which reads them
             self.venv, self.batched = venv, inner.unwrapped
             self._actions = None
+            super().__init__(n_envs, venv.single_observation_space, venv.single_action_space)
             self.render_mode = getattr(inner.unwrapped, "render_mode", None)
 
         # -- reset / step -------------------------------------------------------------------------------------------
@@ -97,6 +98,9 @@ def make_sb3_vec_env(env_id, n_envs, normalize=None, **env_kwargs):
             return [False for _ in self._idx(indices)]
 
         def get_images(self):
+            # the 3D batched env has no render() (PyVista display only in the reference) and render_mode may be None
+            if not callable(getattr(self.batched, "render", None)) or getattr(self.batched, "render_mode", None) is None:
+                return [None] * self.num_envs
             frames = self.batched.render()
             return list(frames) if frames is not None else [None] * self.num_envs
 

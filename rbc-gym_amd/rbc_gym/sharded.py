@@ -55,16 +55,20 @@ class ShardedSim:
         if self._broken is not None:
             raise RuntimeError(f"sharded env is broken after a failed call on one shard ({self._broken}); close it and make a new one")
         futs = [self._pool.submit(fn, r, sim) for r, sim in enumerate(self.sims)]
-        out, first = [], None
+        out, first, failed = [], None, []
         for r, f in enumerate(futs):
             try:
                 out.append(f.result())
             except Exception as e:                      # collect every shard before raising: no call is left in flight
                 out.append(None)
+                failed.append(e)
                 if first is None:
                     first = (r, e)
         if first is not None:
-            if mutating:
+            # An argument check that every shard refuses alike (ValueError / TypeError raised before anything is mutated: a
+            # wrong action shape, a wrong normalisation vector) leaves all shards where they were: the env stays usable.
+            uniform_refusal = len(failed) == len(self.sims) and all(isinstance(e, (ValueError, TypeError)) for e in failed)
+            if mutating and not uniform_refusal:
                 self._broken = f"shard {first[0]} on device {self.devices[first[0]]}: {first[1]}"
             raise first[1]
         return out

@@ -4,7 +4,6 @@ device-resident policies read normalised observations straight from `device_view
 import numpy as np
 
 from .._gym import gym
-from .._native import RbcError
 from .normalize import normalization_bounds, normalize_channels, reward_scale
 from .shaping import cell_distances
 
@@ -59,21 +58,19 @@ class VectorRBCRewardShaping(gym.vector.VectorWrapper):
         super().__init__(env)
         self.shaping_weight = shaping_weight
         self.size_state = env.unwrapped.state_shape
-        self.device_search = True
+        # decided once: the device kernel is built for one wave per mid-line (nx <= 256) of a 2D handle; wider streaming grids and
+        # 3D handles take the numpy search.  Any error of the device path afterwards is a real error and propagates.
+        sim = getattr(env.unwrapped, "sim", None)
+        self.device_search = (hasattr(sim, "get_cell_distances") and len(self.size_state) == 2 and int(self.size_state[1]) <= 256)
 
     def step(self, actions):
         obs, reward, term, trunc, info = self.env.step(actions)
         sim = getattr(self.env.unwrapped, "sim", None)
         cd = None
-        if self.device_search and hasattr(sim, "get_cell_distances"):
+        if self.device_search:
             # the peak search runs on the device, one wave per env, on the float32 state the step kernel just wrote
             # (bit-identical to cell_distances below; only B doubles cross PCIe instead of the mid-lines or the state)
-            try:
-                cd = sim.get_cell_distances(0.001)
-            except RbcError:
-                # the device kernel is built for one wave per mid-line (nx <= 256) of a 2D handle: wider streaming grids and
-                # 3D handles take the numpy search from here on, as before the device path existed
-                self.device_search = False
+            cd = sim.get_cell_distances(0.001)
         if cd is None:
             state = info["state"] if "state" in info else sim.get_state(3)
             cd = cell_distances(state[:, 2, int(self.size_state[0] / 2) - 1])      # UY channel, mid-height row: (B, nx)

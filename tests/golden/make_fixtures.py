@@ -11,6 +11,8 @@ Inputs : /root/reference/data/checkpoints/{train,val,test}/ckpt_ra*.h5
           rbc_sim2D.jl:33-70; h5py sees b,u as (Nz,1,Nx,E) and w as (Nz+1,1,Nx,E), f64)
 Outputs: ckpt2d_ra10000.npz   - 3 episodes of train/ckpt_ra10000 (b,u,w f64)
          ckpt2d_ra100000.npz  - 1 episode of train/ckpt_ra100000
+         ckpt2d_ra{30000,...,10000000}_profiles.npz - per-episode row-wise moments of the 40 episodes per chaotic Ra
+                                (`make_fixtures.py profiles` writes only these)
          ckpt2d_pins.json     - per-file known-answer table (divergence, KE, Nusselt
                                 on the full state and on the 8x48 sensor grid,
                                 horizontal-mean b profile) computed with numpy from the data.
@@ -130,6 +132,38 @@ def spectra():
     print("spectra: |B_2| rows 0..2", mods.mean(0)[0, 1, :3], "rel spread", (mods.std(0, ddof=1)[0, 1, :3] / mods.mean(0)[0, 1, :3]))
 
 
+PROFILE_MOMENTS = ("b", "u2", "w2", "wb", "b2")
+
+
+def row_moments(b, u, w):
+    """per-row means over x of one state (z, x): <b>, <u^2>, <w^2>, <w b>, <b^2> with w at the face BELOW the cell (index k,
+    the convention of get_nusselt, rbc_sim2D_api.jl:142-163) -> (5, nz)"""
+    wc = w[:-1]
+    return np.stack([b.mean(1), (u ** 2).mean(1), (wc ** 2).mean(1), (b * wc).mean(1), (b ** 2).mean(1)])
+
+
+def chaotic_profiles():
+    """ckpt2d_ra{Ra}_profiles.npz for the six chaotic Rayleigh numbers: the row-wise moments above of each of the reference's 40
+    episodes (train 20, val 10, test 10: independent random initial conditions at t = 600, rbc_sim2D.jl:41-43,64-66) --
+    where the boundary layers are 1-2 cells thick these rows are what the near-wall advection stencils decide.  Data only."""
+    for ra in (30000, 100000, 300000, 1000000, 3000000, 10000000):
+        prof, spec, kes, umeans = [], [], [], []
+        for split in ("train", "val", "test"):
+            with h5py.File(f"{REF}/{split}/ckpt_ra{ra}.h5", "r") as f:
+                b = f["b"][...][:, 0]; u = f["u"][...][:, 0]; w = f["w"][...][:, 0]
+            for e in range(b.shape[-1]):
+                prof.append(row_moments(b[..., e], u[..., e], w[..., e]))
+                # which large-scale pattern the episode is in: |W_k| / nx of the mid-height w row, k = 0..8 (translation invariant)
+                spec.append(np.abs(np.fft.rfft(w[w.shape[0] // 2, :, e]))[:9] / w.shape[1])
+                kes.append(0.5 * ((u[..., e] ** 2).mean() + (w[:-1, :, e] ** 2).mean()))
+                umeans.append(u[..., e].mean(1))                       # horizontal-mean (zonal) flow per row
+        prof = np.array(prof)
+        np.savez_compressed(f"{OUT}/ckpt2d_ra{ra}_profiles.npz", profiles=prof, moments=np.array(PROFILE_MOMENTS), ra=np.array(ra),
+                            wmid_spec=np.array(spec), ke=np.array(kes), umean=np.array(umeans))
+        m, se = prof.mean(0), prof.std(0, ddof=1) / np.sqrt(len(prof))
+        print(f"Ra={ra}: {len(prof)} episodes; <b> rows 0..2 {np.round(m[0, :3], 4)} +- {np.round(se[0, :3], 4)}; <w^2> rows 1..3 {np.round(m[2, 1:4], 5)}")
+
+
 def small_h5():
     """ckpt2d_small.h5: 2 episodes of train/ckpt_ra10000 re-written with h5py in the reference
     writer's layout (attrs num_episodes/start_seed, contiguous f64 datasets (Nz[+1],1,Nx,E)) --
@@ -142,5 +176,9 @@ def small_h5():
 
 
 if __name__ == "__main__":
-    main()
-    small_h5()
+    if sys.argv[1:] == ["profiles"]:
+        chaotic_profiles()
+    else:
+        main()
+        small_h5()
+        chaotic_profiles()

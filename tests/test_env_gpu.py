@@ -217,6 +217,13 @@ def test_3d_observation_normalisation_runs_in_the_output_kernel(gym):
     for x, y in zip(raw.sim.get_fields(), fused.unwrapped.sim.get_fields()):
         assert np.array_equal(x, y)
     assert fused.observation_space.shape == (3, 4, 16, 32, 32) and np.abs(o_f).max() <= 1.0
+    # a blown-up env: np.clip hands a NaN through, and so does the kernel's clip (fminf / fmaxf alone would return -maxval)
+    sim = fused.unwrapped.sim
+    f = [x.copy() for x in sim.get_fields()]
+    f[0][1, 3, 4, 5] = np.nan
+    sim.reset_from_arrays(*f)
+    got = sim.get_state()
+    assert np.isnan(got[1, 0, 3, 4, 5]) and np.isfinite(got[0]).all() and sim.get_flags()[1] == 1
     raw.close(); fused.close()
 
 
@@ -233,6 +240,13 @@ def test_sb3_vec_env_adaptor(gym, monkeypatch):
             self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
             self.reset_infos = [{} for _ in range(num_envs)]
             self._seeds = [None for _ in range(num_envs)]
+            self._options = [{} for _ in range(num_envs)]
+            modes = self.get_attr("render_mode")               # SB3 2.x reads the sub-envs' render mode in its constructor
+            assert all(m == modes[0] for m in modes)
+            self.render_mode = modes[0]
+
+        def _reset_options(self):
+            self._options = [{} for _ in range(self.num_envs)]
 
         def seed(self, seed=None):
             self._seeds = [seed + i for i in range(self.num_envs)]
@@ -254,6 +268,7 @@ def test_sb3_vec_env_adaptor(gym, monkeypatch):
     kw = dict(state_shape=(16, 32, 32), heater_duration=0.0625, episode_length=0.5, rayleigh_number=5000)
     ve = make_sb3_vec_env(ID3, n_envs=3, normalize=dict(heater_limit=0.9, u_limit=None), **kw)
     assert isinstance(ve, VecEnv) and ve.num_envs == 3 and ve.action_space.shape == (8, 8) and ve.observation_space.shape == (4, 16, 32, 32)
+    assert ve.get_images() == [None, None, None]                   # the 3D env has no frames to hand to SB3's video recorder
     ve.seed(11)
     obs0 = ve.reset()
     assert obs0.shape == (3, 4, 16, 32, 32) and len(ve.reset_infos) == 3 and ve.reset_infos[0]["step"] == 1
@@ -586,10 +601,54 @@ def test_ra_sweep_ensembles_match_the_reference_episode_statistics():
         assert abs(z(ra, "ke")) < 4.0, (ra, got[ra]["ke"].mean(), ref[ra]["ke"].mean())
         assert abs(z(ra, "nusselt_state")) < 4.0 and abs(z(ra, "wmax")) < 4.5 and abs(z(ra, "umax")) < 4.5, ra
     assert abs(got[3000000]["ke"].mean() / ref[3000000]["ke"].mean() - 1) < 0.01      # the narrowest chaotic distribution (std 1.4 %)
-    assert abs(got[10000000]["ke"].mean() / ref[10000000]["ke"].mean() - 1) < 0.05
+    # Ra = 1e7 is the one KNOWN statistical disagreement with reference data (round 4, tests/golden/profile_pin_gpu.txt, 1024 members):
+    # kinetic energy +2.4 % (z = +4.3 ... +4.6), a uniform offset of <u^2> and <w^2> in the BULK rows (the k = 2 roll pair is 1.4 %
+    # stronger) with every wall row, <b>, <b^2> and <w b> inside the noise, the lower half of the distribution equal to the
+    # reference's (5 % / 25 % quantiles 0.1889 / 0.1928 against 0.1890 / 0.1913) and a heavier upper tail; the same with half the
+    # solver step, with the other wall-stencil variant and under the generator's re-entry protocol.  Pinned as measured, not waved through:
+    ratio = got[10000000]["ke"].mean() / ref[10000000]["ke"].mean()
+    assert 1.0 < ratio < 1.05 and 0.0 < z(10000000, "ke") < 7.0, (ratio, z(10000000, "ke"))
+    q_mine, q_ref = np.quantile(got[10000000]["ke"], [0.05, 0.25]), np.quantile(ref[10000000]["ke"], [0.05, 0.25])
+    assert np.all(np.abs(q_mine / q_ref - 1) < 0.015), (q_mine, q_ref)
     assert abs(z(10000000, "nusselt_state")) < 4.0
     k2 = np.abs(got[10000]["ke"] - ref[10000]["ke"].mean()) < 1e-4            # Ra=1e4: steady; see the from-rest ensemble test
     assert k2.sum() > 0.8 * k2.size and abs(got[10000]["ke"][k2].mean() / ref[10000]["ke"].mean() - 1) < 3e-6
+
+
+def test_row_profiles_at_the_chaotic_rayleigh_numbers_match_the_reference_episodes():
+    """Where the [RECALL] wall stencils matter most: at Ra >= 1e6 the thermal boundary layer is one to two cells
+    thick (the reference's bottom-row <b> is 1.887 at Ra = 1e6, 1.719 at 1e7 under a plate at 2).  Per-row means over x of b, u^2,
+    w^2, w b, b^2 of the reference's 40 episodes per Ra (tests/golden/ckpt2d_ra*_profiles.npz, made from its HDF5 files by
+    make_fixtures.py) against 128 members per Ra of the product at the generator's protocol, Welch z per row and moment (320 per
+    Ra; rows are correlated, so the bar is on max and rms, as for the Ra = 1e4 spectral pin).  Recorded with 1024 members
+    (tests/golden/profile_pin_gpu.txt): Ra = 3e4 ... 3e6 max |z| 1.1 / 1.1 / 2.7 / 1.7 / 2.7, rms 0.6 ... 1.5, the eight wall
+    rows never beyond 2.5.  HONEST LIMIT: the build with the rejected advecting-velocity rule (-DRBC_SYMLEVEL=1) scores the
+    same here (max 1.1 / 1.1 / 2.6 / 2.4 / 2.9) -- 40 chaotic episodes do not resolve what separates the variants; the Ra = 1e4
+    steady state does (spectral pin: 1.9 against 103).  Ra = 1e7: wall rows, <b>, <b^2>, <w b> inside the same bars; <u^2> and
+    <w^2> of the bulk rows 3-5 % high (z up to 5.4): the kinetic-energy offset of the sweep test, asserted there."""
+    import importlib.util
+    import profile_pins as pp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("profile_pin", os.path.join(root, "scripts", "profile_pin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ens, _ = mod.run(list(pp.CHAOTIC_RAS), 128, "env", seed0=515)
+    line = []
+    for ra in pp.CHAOTIC_RAS:
+        z, _ = pp.profile_z(ens[ra], pp.reference_profiles(ra))
+        nz = z.shape[1]
+        wall = np.r_[0:4, nz - 4:nz]
+        zmax, zrms = pp.summarise(z)
+        line.append(f"{ra}: {zmax:.1f}/{zrms:.2f}")
+        assert np.abs(z[:, wall]).max() < 4.5, (ra, np.round(z[:, wall], 1))          # the rows the wall stencils decide
+        if ra < 10000000:
+            assert zmax < 5.0 and zrms < 2.0, (ra, zmax, zrms)
+        else:
+            for m in (0, 3, 4):                                                        # <b>, <w b>, <b^2>
+                assert np.abs(z[m]).max() < 4.5, (ra, pp.MOMENTS[m], np.abs(z[m]).max())
+            bulk = slice(12, nz - 12)
+            assert 0.0 < z[1, bulk].mean() < 7.0 and 0.0 < z[2, bulk].mean() < 7.0, (z[1, bulk].mean(), z[2, bulk].mean())
+    print("row profiles, max |z| / rms z per Ra:", "  ".join(line))
 
 
 def test_3d_vector_env_matches_single_envs_and_autoresets(gym):

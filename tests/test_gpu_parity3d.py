@@ -203,8 +203,7 @@ def test_float32_3d_within_stated_tolerances_of_the_float64_oracle(native, o3):
     """rbc_config.precision = float32 on the 3D path (the rbc3f instantiation of every streaming kernel; rbc3D.py:229-232 hands
     out float32 observations anyway) at BASELINE.json configs[4]'s shape, from a DEVELOPED convecting state, one env-step of 13
     substeps.  Stated tolerances against the float64 oracle on the identical initial fields (float32-rounded on upload):
-    tendencies 2e-5 of their maximum, b 1e-6 rel-L2, u, v, w 1e-4, Nusselt number 1e-5; divergence at float32 round-off.  The
-    deferred vertical correction (RBC_DEFER_W=1) and the separate pass agree to float32 round-off."""
+    tendencies 2e-5 of their maximum, b 1e-6 rel-L2, u, v, w 1e-4, Nusselt number 1e-5; divergence at float32 round-off."""
     shape, ra, B = (32, 48, 48), 1e4, 2
     gen = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, random_kick=0.1)
     gen.reset(np.array([11, 12], dtype=np.uint64))
@@ -243,20 +242,6 @@ def test_float32_3d_within_stated_tolerances_of_the_float64_oracle(native, o3):
     t, s = sim.get_info()
     assert np.allclose(t, 0.5) and np.all(s == 2)
     sim.close()
-    import os
-    outs = []
-    for flag in ("0", "1"):
-        os.environ["RBC_DEFER_W"] = flag
-        try:
-            s2 = native.NativeSim3D(batch=B, shape=shape, ra=ra, dt_control=0.125, dt_solver=0.01, precision="f32")
-            s2.reset_from_arrays(*ics)
-            assert s2.step(act) and s2.step(act)
-            outs.append(s2.get_fields())
-            s2.close()
-        finally:
-            del os.environ["RBC_DEFER_W"]
-    for x, y in zip(*outs):
-        assert rel_l2(x, y) < 2e-6
 
 
 def test_float32_3d_flowstats_statistics(native):
@@ -616,30 +601,6 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
         for x, y in zip(f, outs[0][0]):
             assert rel_l2(x, y) < 1e-12
     assert len({float(x) for x in outs[0][1]}) == B             # 16 different envs, not copies
-
-
-def test_deferred_vertical_correction_agrees_with_the_separate_pass(native, monkeypatch):
-    """RBC_DEFER_W=1 (an experiment kept off by default: parity-green but slower in both precisions, rbc3d_host_body.hpp): w -= dts dphi/dz of a
-    stage's projection is applied by the NEXT stage's tile kernels as they load w (planes and own-column windows) instead of
-    the k3_correct_w pass.  Same expression on the same operands: round-off agreement over two env-steps incl. a clipped last
-    substep, on the constant-grid (48 x 48), the generic (40 x 48 -> 8 x 8 tiles) and the registry-default instantiations."""
-    for B, shape in ((8, (32, 48, 48)), (2, (16, 32, 32)), (4, (16, 48, 40))):
-        act = np.random.default_rng(B).uniform(-1, 1, (2, B, 8, 8)).astype(np.float32)
-        outs = []
-        for flag in ("0", "1"):
-            monkeypatch.setenv("RBC_DEFER_W", flag)
-            sim = native.NativeSim3D(batch=B, shape=shape, domain=DOMAIN, ra=8000.0, dt_control=0.035, dt_solver=0.01, random_kick=0.2)
-            sim.reset(np.arange(7, 7 + B, dtype=np.uint64))
-            for n in range(2):
-                assert sim.step(act[n])
-            outs.append((sim.get_fields(), sim.get_nusselt()))
-            sim.close()
-        monkeypatch.delenv("RBC_DEFER_W")
-        for x, y in zip(outs[0][0], outs[1][0]):
-            assert rel_l2(x, y) < 1e-12, shape
-        assert np.allclose(outs[0][1], outs[1][1], rtol=1e-10)
-        b, u, v, w = outs[1][0]
-        assert np.all(w[:, 0] == 0) and np.all(w[:, -1] == 0)
 
 
 def test_constant_grid_instantiations_agree_with_the_generic_ones(native, monkeypatch):

@@ -125,6 +125,38 @@ def test_oracle_stays_on_the_reference_attractor(ckpt_ra1e4, pins):
     assert t == 6.0 and step == 5
 
 
+def test_the_lost_solver_step_of_a_run_reentry_is_lost_time_not_lost_amplitude(ckpt_ra1e4, pins):
+    """The reference's recorded series carry the growth of one solver step less per `run!` re-entry (DESIGN.md section 4;
+    `reference_clock="recorded"`).  In the linear phase a loss of TIME (one solver step not taken) and a loss of AMPLITUDE
+    (perturbations scaled by e^-0.006, i.e. Nu - 1 by e^-0.012, once per re-entry) fit those series equally well.  The
+    reference's own 2D checkpoints tell them apart: their generator re-enters `run!` every 10 solver steps
+    (rbc_sim2D.jl:189-194 with --delta_t_snap 0.3, scripts/create_checkpoints_2D.sh:18-20), 2000 times per episode, and its 40
+    stored Ra = 1e4 states sit on ONE steady state (kinetic energy spread 6e-7).  A time loss leaves a fixed point where it
+    is; an amplitude loss per re-entry moves it to where the flow regrows the loss every 10 steps.  Here both on the oracle,
+    from a stored state: 9 instead of 10 solver steps per re-entry stays inside the 40-episode band, the amplitude factor
+    leaves it by four orders of magnitude more than the band is wide.  So the recorded loss is a loss of time."""
+    eps = [e for sp in ("train", "val", "test") for e in pins[f"{sp}/ckpt_ra10000"]["episodes"]]
+    ke = np.array([e["ke"] for e in eps])
+    cond = (1.0 + (2.0 - (np.arange(64) + 0.5) / 32.0) * 0.5)[:, None]        # conduction profile min_b + (Lz - z) delta_b / 2
+
+    def reentries(nsub, factor, n):
+        s = OracleSim(ra=1e4)
+        s.reset_from_arrays(ckpt_ra1e4["b"][0], ckpt_ra1e4["u"][0], ckpt_ra1e4["w"][0])
+        for _ in range(n):
+            s.set_action(np.zeros(12, np.float32)); s.update_state()
+            for _ in range(nsub):
+                s.substep(0.03)
+            if factor != 1.0:
+                b, u, w = s.fields()
+                s.load_raw(cond + (b - cond) * factor, u * factor, w * factor)
+        return s.kinetic_energy()
+
+    time_loss = reentries(9, 1.0, 30)
+    amp_loss = reentries(10, np.exp(-0.006), 30)
+    assert ke.min() - 1e-6 < time_loss < ke.max() + 1e-6, time_loss
+    assert ke.mean() - amp_loss > 5e-3 > 1000 * (ke.max() - ke.min()), (amp_loss, ke.mean())
+
+
 def test_recorded_ensemble_pin(golden_dir):
     """The slow from-rest ensemble (tests/golden/oracle_ensemble.py, run by hand, result committed):
     12 independent oracle runs to t=600 vs the 40 Oceananigans episodes."""

@@ -79,6 +79,46 @@ def test_two_ranks_reproduce_one_process():
         assert merged[i] == serial[i]                       # bitwise: no cross-env coupling anywhere
 
 
+def _worker8(rank, world, port, q):
+    """the reductions of the N = 8 bench line with nothing but the host: shards of BASELINE.json configs[2] (8192 envs over 8 GPUs)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, count = sharding.shard(8192, world, rank)
+    seeds = sharding.env_seeds(1234, start, count)
+    sharding.barrier(dist)
+    elapsed, nans = sharding.reduce_run(0.5 + 0.01 * rank, rank % 2, dist=dist)
+    per_rank = sharding.gather_run(0.5 + 0.01 * rank, rank % 2, dist=dist)
+    q.put((rank, start, count, int(seeds[0]), int(seeds[-1]), elapsed, nans, per_rank))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_reductions_of_the_scale_line():
+    """world_size 8 over gloo on the CPU: the shards of configs[2] tile the 8192 envs, seeds run on across the shard boundaries,
+    `value` would use the slowest rank, `per_rank` lists all eight.  (On the GPU box at most six processes may touch the card,
+    so the GPU rehearsal of the self-launching bench, tests/test_bench_contract.py, runs five ranks next to the test runner; the
+    eight-rank case is covered here without a GPU and by the driver on a real node.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    nxt = 0
+    for rank, start, count, s0, s1, elapsed, nans, per_rank in got:
+        assert (start, count) == (nxt, 1024) and (s0, s1) == (1234 + start, 1234 + start + 1023)
+        nxt += count
+        assert abs(elapsed - 0.57) < 1e-12 and nans == 4
+        assert np.allclose(per_rank[0], [0.5 + 0.01 * r for r in range(8)]) and per_rank[1] == [0, 1] * 4
+    assert nxt == 8192
+
+
 class _FakeSim:
     """stand-in for NativeSim in the host-logic test of rbc_gym.sharded.ShardedSim: env e of the global batch holds the
     value `100 * device + local index`, a step adds the env's action sum; records the thread it was driven from"""
@@ -171,12 +211,19 @@ def test_sharded_sim_marks_itself_broken_after_a_failed_mutating_call():
         def get_flags(self):
             return np.zeros(self.count, np.int32)
 
+        def set_obs_normalization(self, lo, hi):
+            if len(lo) != len(hi):
+                raise ValueError("min_vals and max_vals must be of equal length")      # refused before anything is mutated
+
         def close(self):
             self.closed = True
 
     s = ShardedSim(Fake, 5, devices=[0, 1])
     acts = np.zeros((5, 12), np.float32)
     assert s.step(acts) is True
+    with pytest.raises(ValueError):                                     # every shard refuses the same bad argument: nothing diverged
+        s.set_obs_normalization([0, 0, 0], [1, 1])
+    assert s.get_flags().shape == (5,)                                  # ... so the env stays usable
     with pytest.raises(RuntimeError, match="device lost"):
         s.step(acts)
     assert [f.steps for f in s.sims] == [2, 1]                         # the healthy shard went ahead: the batch is inconsistent
