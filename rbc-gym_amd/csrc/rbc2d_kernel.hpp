@@ -101,6 +101,11 @@ struct Params2D {
     int obs_nx, obs_nz;
     int obs_norm, obs_clip;    // rbc_set_obs_normalization: channels [0, obs_norm) of obs are normalised
     float obs_min[5], obs_rng[5], obs_maxval;
+    // (kept at the END of the struct: the one-env kernels never read them and keep their argument offsets)
+    // float copies of the uniform constants for the packed float32 variant: converted on the host they arrive as SCALAR kernel arguments
+    // and are broadcast by op_sel where they are used; converted in the kernel (v_cvt_f32_f64) each one is a VGPR for the whole launch --
+    // a dozen of them in a kernel that sits at its 168-register cap.  cpf = (rdz * rdz) * NX in float, the z sweeps' off-diagonal factor.
+    float f_dx, f_dz, f_rdx, f_rdz, f_rdx2, f_rdz2, f_rhz, f_min_b, f_dt, f_dt_last, f_cpf;
 };
 
 // RBCNormalizeObservation.observation (rbc_normalize_observation.py:66-74) on one float32 sample: the same
@@ -313,6 +318,9 @@ template <typename T> struct LaneT { static constexpr int N = 1; typedef T S; };
 template <> struct LaneT<f32x2> { static constexpr int N = 2; typedef float S; };
 template <typename T> __device__ __forceinline__ T bc(double x) { return (T)x; }                  // a double constant in every lane
 template <> __device__ __forceinline__ f32x2 bc<f32x2>(double x) { return f32x2((float)x); }
+// the same for a constant that exists in both precisions (Params2D: double for the one-env kernels, float for the packed variant)
+template <typename T> __device__ __forceinline__ T bc2(double d, float) { return (T)d; }
+template <> __device__ __forceinline__ f32x2 bc2<f32x2>(double, float f) { return f32x2(f); }
 __device__ __forceinline__ double lane(double x, int) { return x; }
 __device__ __forceinline__ float lane(float x, int) { return x; }
 __device__ __forceinline__ float lane(f32x2 x, int e) { return e ? x.y : x.x; }
@@ -361,7 +369,11 @@ struct Geo {
     }
     static constexpr int TSPLIT = tsplit();
     static constexpr int ZTAIL = ((TROWS - TSPLIT) * NH + NX > GUARD * RS) ? (TROWS - TSPLIT) * NH + NX - GUARD * RS : 0;
-    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH + 3 * NCELL + GUARD * RS + ZTAIL) * sizeof(T);
+    // packed variant: the per-env pairs (nu, kappa) -- scalars of the workgroup in the one-env kernels, VGPR pairs that live (spilled) through
+    // the whole launch otherwise -- sit behind the tail and are read where a pass needs them
+    static constexpr int XTRA = (LaneT<T>::N > 1) ? 2 : 0;
+    static constexpr int XOFF = 3 * NCELL + GUARD * RS + ZTAIL;           // relative to the first field row
+    static constexpr size_t LDS_BYTES = (size_t)(SCRATCH + 3 * NCELL + GUARD * RS + ZTAIL + XTRA) * sizeof(T);
     static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
     static constexpr size_t ENV_STRIDE = (size_t)(3 * NZ + 1) * NX;   // doubles per env in `fields`
     // workgroups that share a CU (LDS and the 2048-thread limit decide) -> waves per SIMD the register allocation must allow
@@ -420,7 +432,7 @@ template <int NX, int NZ, typename T>
 __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict__ tw,
                                         const double *__restrict__ tri_inv, T dts, T rdx, T rdz,
                                         int tid_in, unsigned long long *stamp_acc, unsigned long long &stamp_last,
-                                        T (&un)[CZ], T (&wn)[CZ])
+                                        T (&un)[CZ], T (&wn)[CZ], float cpf_host = 0.0f)
 {
     using G = Geo<NX, NZ, T>;
     constexpr int RS = G::RS, FU = G::FU, FW = G::FW, FB = G::FB, N2 = G::N2;
@@ -519,7 +531,11 @@ __device__ __forceinline__ void project(T *__restrict__ lds, const T *__restrict
     const bool sw_up = tid < NX, sw_dn = (tid >= NXP) && (tid < NXP + NX);
     const int tj = sw_up ? tid : tid - NXP;
     const int tm = min(tj, NX - tj);
-    const T cpf = rdz * rdz * bc<T>((double)NX);                // cp_k = tab_k * cpf
+    // cp_k = tab_k * cpf.  Packed pairs: computed here the product is a loop-invariant VGPR pair that hipcc hoists out of the stage loop,
+    // spills, and reloads from scratch at the head of both z sweeps -- on the serial recurrence of the phase in which four waves work;
+    // the host hands the same float product over as a kernel argument, which stays a scalar operand.
+    T cpf;
+    if constexpr (LaneT<T>::N > 1) cpf = bc2<T>(0.0, cpf_host); else cpf = rdz * rdz * bc<T>((double)NX);
     const int tp = (tj == 0) ? 0 : NX - tj;                   // junction partner column (mode NX-m)
     T *colb = lds + FB + mode_pos<N2>(tj);
     T *jctA = tabA + TSPLIT * G::NH, *jctB = tabB + TROWS * G::NH;
@@ -705,8 +721,9 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     const int k0 = c * CZ;
     const bool top = (c == G::NC - 1);
 
-    const real dx = bc<real>(P.dx), dz = bc<real>(P.dz), rdx = bc<real>(P.rdx), rdz = bc<real>(P.rdz), rdx2 = bc<real>(P.rdx2), rdz2 = bc<real>(P.rdz2);
-    const real min_b = bc<real>(P.min_b);
+    const real dx = bc2<real>(P.dx, P.f_dx), dz = bc2<real>(P.dz, P.f_dz), rdx = bc2<real>(P.rdx, P.f_rdx), rdz = bc2<real>(P.rdz, P.f_rdz),
+               rdx2 = bc2<real>(P.rdx2, P.f_rdx2), rdz2 = bc2<real>(P.rdz2, P.f_rdz2);
+    const real min_b = bc2<real>(P.min_b, P.f_min_b);
     real nu, kap, Tb;
     real bn[CZ];
     if (tid < NX) {                  // N2 * 8 = NX twiddles
@@ -794,6 +811,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     if (!any_live) return;
 #pragma unroll
     for (int e = 0; e < NL; ++e) { set_lane(nu, e, (scal)P.nu_kappa[2 * envs[e]]); set_lane(kap, e, (scal)P.nu_kappa[2 * envs[e] + 1]); }
+    if (tid == 0) { lds[G::XOFF] = nu; lds[G::XOFF + 1] = kap; }      // read back per pass (NU / KAP below); a barrier precedes the stage loop
 
     double *gf[NL];
 #pragma unroll
@@ -880,7 +898,9 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     // inside the stage loop makes the s_waitcnt in front of it a vmcnt(0) that also waits for the park loads just issued
     auto park = [&](int f) -> dbl2 * { return reinterpret_cast<dbl2 *>(gpark + (((size_t)blockIdx.x * 2 + f) * G::NT + opaque(tid)) * CZ); };
 
-    const real rhz = bc<real>(P.rhz);   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
+    const real rhz = bc2<real>(P.rhz, P.f_rhz);   // 1/(dz/2); dz/2 is a power of two at the reference sizes, so *rhz == /(dz/2) bitwise
+    auto NU = [&]() -> real { if constexpr (NL == 1) return nu; else return lds[G::XOFF]; };
+    auto KAP = [&]() -> real { if constexpr (NL == 1) return kap; else return lds[G::XOFF + 1]; };
     const int nstage = (P.mode == MODE_STEP) ? 3 * P.nsub : ((P.mode == MODE_TENDENCY) ? 1 : 0);
 
     if (P.mode == MODE_PROJECT || P.mode == MODE_RANDOM) {
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
         lds_barrier();
 #pragma unroll
         for (int r = 0; r < CZ; ++r) { u0[r] = lds[(k0 + r) * RS + FU + i]; w0[r] = lds[(k0 + r) * RS + FW + i]; }
-        project<NX, NZ, T>(lds, tw, P.tri_inv, real(1), rdx, rdz, tid, stamp_acc, stamp_last, u0, w0);
+        project<NX, NZ, T>(lds, tw, P.tri_inv, real(1), rdx, rdz, tid, stamp_acc, stamp_last, u0, w0, P.f_cpf);
         // the b slot now holds phi (pNHS); b stays in registers
     } else {
         lds_barrier();
@@ -904,7 +924,8 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
     STAMP(0);
     for (int st = 0; st < nstage; ++st) {
         const int sub = st / 3, ph = st - 3 * sub;
-        const real dt = bc<real>((sub == P.nsub - 1) ? P.dt_last : P.dt);
+        const bool last_sub = (sub == P.nsub - 1);
+        const real dt = bc2<real>(last_sub ? P.dt_last : P.dt, last_sub ? P.f_dt_last : P.f_dt);
         // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl)
         const real gam = (ph == 0) ? real(8.0 / 15.0) : (ph == 1 ? real(5.0 / 12.0) : real(3.0 / 4.0));
         const real zet = (ph == 0) ? real(0.0) : (ph == 1 ? real(-17.0 / 60.0) : real(-5.0 / 12.0));
@@ -1017,7 +1038,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
                     }
                     const real adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
                     // -d_j tau_1j, tau = -2 nu Sigma ([OC] TurbulenceClosures, isotropic ScalarDiffusivity)
-                    const real vis = nu * (real(2) * ((up1 - u0) - (u0 - um1)) * rdx2
+                    const real vis = NU() * (real(2) * ((up1 - u0) - (u0 - um1)) * rdx2
                                              + (((uup - u0) * rdz + (wc_hi - wm_hi) * rdx) - ((u0 - udn) * rdz + (wc_lo - wm_lo) * rdx)) * rdz);
                     // hydrostatic pressure gradient
                     const real d = cc0[r * RS + FB] - cm1[r * RS + FB];
@@ -1072,7 +1093,7 @@ __global__ __launch_bounds__(NX *(NZ / CZ), (Geo<NX, NZ, T>::WAVES_PER_SIMD)) vo
                         bup = wall ? (b0 + ((min_b - b0) * rhz) * dz) : w3;
                     }
                     const real adv = (fx_e - fx_i) * rdx + (fz_hi - fz_lo) * rdz;
-                    const real dif = kap * (((bp1 - b0) - (b0 - bm1)) * rdx2 + ((bup - b0) - (b0 - bdn)) * rdz2);
+                    const real dif = KAP() * (((bp1 - b0) - (b0 - bm1)) * rdx2 + ((bup - b0) - (b0 - bdn)) * rdz2);
                     const real g = dif - adv;
                     if (dbg) dg[(k0 + r) * NX + i] = (double)lane(g, 0);
     #if RBC_EXPERIMENT_NOG0
@@ -1142,7 +1163,7 @@ dbl2 *pk = park(0);
                         const real fx_w = upw5(ut_w, wm3, wm2, wm1, wc, wp1, wp2);
                         const real fx_e = upw5(ut_e, wm2, wm1, wc, wp1, wp2, wp3);
                         const real adv = (fx_e - fx_w) * rdx + (fz_hi - fz_lo) * rdz;
-                        const real vis = nu * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
+                        const real vis = NU() * ((((e2 - e1) * rdz + (wp1 - wc) * rdx) - ((a2 - a1) * rdz + (wc - wm1) * rdx)) * rdx
                                                  + real(2) * ((w3 - wc) - (wc - w1)) * rdz2);
                         g = ((r == 0) && bot) ? real(0) : (vis - adv);
                     }
@@ -1181,7 +1202,7 @@ dbl2 *pk = park(1);
 #if RBC_EXPERIMENT_NOPROJECT
         lds_barrier();          // timing experiment only (WRONG numerics): what the stage costs without the Poisson solve
 #else
-        project<NX, NZ, T>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last, un, wn);
+        project<NX, NZ, T>(lds, tw, P.tri_inv, dts, rdx, rdz, tid, stamp_acc, stamp_last, un, wn, P.f_cpf);
 #endif
         STAMP(12);
         if (st + 1 < nstage) {

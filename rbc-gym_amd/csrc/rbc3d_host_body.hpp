@@ -35,6 +35,7 @@ struct rbc3_state {
     int fuse2d = 0;                    // streaming-2D: N1 of the one-kernel projection (k2s_project_fused), 0 = the separate kernels
     size_t fuse2d_lds = 0;
     int fft_threads = 256;             // slab-FFT workgroup: one round of work items for the larger of nx, ny (8 items per line)
+    int march = 0;                     // 3D: 2 = k3_ifft_march (inverse FFT + the whole correction), 0 = k3_ifft_pair + k3_correct_w
     double tff = 1.0;
     // Le-Moin RK3 ([OC] TimeSteppers/runge_kutta_3.jl).  Builds made with -DRBC_EXPERIMENTS=1 (never the shipped library) read
     // RBC_EXPERIMENT_RK3="g1,g2,g3,z2,z3" for the "does the flowstats pin discriminate the time integrator" experiment.
@@ -260,6 +261,18 @@ int create3d(rbc_handle *h)
             HIP3(hipEventCreateWithFlags(&s->gstart, hipEventDisableTiming));
         }
     }
+    // 3D, mirror-packed path, float64: the inverse FFT marches 2 adjacent slab pairs per workgroup and applies the vertical correction
+    // itself (k3_ifft_march).  Measured at configs[4], three interleaved repeats on one box (scripts/ab_march.sh): float64 6.28k ->
+    // 6.69k env-steps/s (+6.6 %; 1 pair per workgroup, i.e. every pair transformed twice: +5.3 %; 4 pairs: -3 %; 8: -21 % -- the
+    // workgroups are latency-bound, a longer serial chain costs more than the saved transforms); float32 9.36k -> 9.10k (-2.8 %; 1
+    // pair: -1.2 %), so float32 keeps k3_ifft_pair + k3_correct_w.  RBC_IFFT_MARCH=0 | 2 overrides (0: the A/B partner, bitwise the
+    // same state; also what the streaming-2D grids run).
+    if (!h->stream2d && c.nz % 4 == 0 && !h->no_pair && (size_t)c.nx * ny <= (size_t)8 * s->fft_threads) {
+        int m = std::is_same<real, double>::value ? 2 : 0;
+        if (const char *e = std::getenv("RBC_IFFT_MARCH")) m = std::atoi(e);
+        s->march = (m == 2) ? 2 : 0;
+    }
+    RBC_LDS_ATTR((K3::k3_ifft_march<2, 4>)); RBC_LDS_ATTR((K3::k3_ifft_march<2, 6>)); RBC_LDS_ATTR((K3::k3_ifft_march<2, 8>));
     RBC_LDS_ATTR(K3::k3_rhs_fft);
     RBC_LDS_ATTR(K3::k3_ifft);
     RBC_LDS_ATTR(K3::k3_rhs_fft_pair);
@@ -336,6 +349,15 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
         if (s->ip2d) { RBC_IP_INV(4) RBC_IP_INV(6) RBC_IP_INV(8) RBC_IP_INV(12) RBC_IP_INV(16) RBC_IP_INV(24) RBC_IP_INV(32) }
         else
         if (s->rows2d) hipLaunchKernelGGL(K3::k2s_ifft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
+        else if (s->march) {            // inverse FFT + the WHOLE correction, two slab pairs per workgroup: no k3_correct_w, no phi
+            const dim3 gr(B * (g.nz / 4));
+            const int np = (int)((pln + s->fft_threads - 1) / s->fft_threads);        // columns per thread: 4, 6 or 8
+#define RBC_MARCH(CH_, NP_) hipLaunchKernelGGL((K3::k3_ifft_march<CH_, NP_>), gr, dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, buf, dts, mk)
+            if (np <= 4) RBC_MARCH(2, 4); else if (np <= 6) RBC_MARCH(2, 6); else RBC_MARCH(2, 8);
+#undef RBC_MARCH
+            HIP3(hipGetLastError());
+            return RBC_OK;
+        }
         else hipLaunchKernelGGL(K3::k3_ifft_pair, dim3(B * (g.nz / 2)), dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, phi, buf, dts, mk);
 #if RBC_EXPERIMENTS      /* timing bound only (WRONG numerics): what a stage costs without the separate vertical correction */
         static const bool skip_cw = [] { const char *e = std::getenv("RBC_EXPERIMENT_SKIP_CW"); return e && e[0] == '1'; }();

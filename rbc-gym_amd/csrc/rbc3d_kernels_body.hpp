@@ -1334,6 +1334,101 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const real2 *spec, real *phi, r
     }
 }
 
+// The whole correction in the inverse-FFT kernel (round 4): a workgroup MARCHES over CH adjacent packed slab pairs p = k0 .. k0+CH-1
+// of one env.  The vertical correction of face f needs phi of the cells below and above it, at the SAME column -- and with mirror
+// packing both neighbours of a face live in ADJACENT pairs: face p (lower half) needs Re of pairs p-1 and p, face nz-p (upper half)
+// needs Im of pairs p and p-1, and the junction face nz/2 is Im - Re of pair nz/2-1 alone.  So every thread keeps the (normalised)
+// packed potential of the previous pair at the columns it owns in registers (pln / blockDim complex values) and applies
+//     w(p)    -= (Re phi_p - Re phi_{p-1}) rdz dts,      w(nz-p) -= (Im phi_{p-1} - Im phi_p) rdz dts
+// right after the horizontal half, with the same expression and operand order as k3_correct_w: bit for bit the same state.  A
+// chunk that does not start at the wall transforms pair k0-1 once more to seed its registers ((CH+1)/CH of the FFT work); the
+// k3_correct_w launch, its read of w and two reads of phi, and the store of phi (never an output of a 3D env) are gone.
+// Timing bound measured before this kernel existed (a build that simply skips k3_correct_w, wrong numerics): +8.3 % float64,
+// +6.3 % float32 at configs[4]; realised with CH = 2: +6.6 % float64 (rbc3d_host_body.hpp, create3d, has the sweep over CH).
+template <int CH, int NP>                                        // NP: columns a thread owns, pln <= NP * blockDim (chosen by the host)
+__global__ void __launch_bounds__(512, 3) k3_ifft_march(Geo3 g, FftPlan pl, const real2 *spec, real *st, real dts, const uint8_t *mask)
+{
+    extern __shared__ __attribute__((aligned(16))) real2 sm[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2, nchunk = half / CH;
+    const int env = blockIdx.x / nchunk, k0 = (blockIdx.x - env * nchunk) * CH;
+    if (mask && !mask[env]) return;
+    const int nxp = slab_row(nx), lpl = nxp * ny;
+    real2 *A = sm, *T = sm + lpl, *twx = sm + 2 * lpl, *twy = twx + nx;
+    for (int t = threadIdx.x; t < nx + ny; t += blockDim.x) twx[t] = pl.tw[t];
+    const real sc = real(1.0) / (real)pln;
+    real *sb = st + (size_t)env * g.env_stride;
+    real *ub = sb + g.nc, *vb = sb + 2 * (size_t)g.nc, *wb = sb + 3 * (size_t)g.nc;
+    const int s0 = (k0 > 0) ? -1 : 0;
+    real2 prev[NP], nxt[NP];                                       // potential of the previous pair / spectrum of the next one, own columns
+    {
+        const real2 *in = spec + ((size_t)env * half + (k0 + s0)) * pln;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int idx = threadIdx.x + q * blockDim.x;
+            prev[q] = make_real2(real(0.0), real(0.0));
+            nxt[q] = (idx < pln) ? in[idx] : make_real2(real(0.0), real(0.0));
+        }
+    }
+    for (int s = s0; s < CH; ++s) {
+        const int p = k0 + s, pm = nz - 1 - p;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int idx = threadIdx.x + q * blockDim.x;
+            if (idx < pln) { const int j = idx / nx; A[idx + j * (nxp - nx)] = nxt[q]; }
+        }
+        if (s + 1 < CH) {                                         // the next pair's spectrum flies under this pair's transform
+            const real2 *in = spec + ((size_t)env * half + (p + 1)) * pln;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { const int idx = threadIdx.x + q * blockDim.x; if (idx < pln) nxt[q] = in[idx]; }
+        }
+        __syncthreads();
+        slab_fft2d(A, T, nx, ny, pl, twx, twy, +1);
+        if (s >= 0) {
+            real *ulo = ub + (size_t)p * pln, *uhi = ub + (size_t)pm * pln, *vlo = vb + (size_t)p * pln, *vhi = vb + (size_t)pm * pln;
+            real *wlo = wb + (size_t)p * pln, *whi = wb + (size_t)(nz - p) * pln, *wj = wb + (size_t)half * pln;      // faces p, nz - p, nz/2
+            const bool low = (p > 0), jct = (p == half - 1);      // the wall faces 0 and nz carry no correction
+            // all global loads of a batch first (six waves have little else to hide their latency), then the updates
+            constexpr int UB = 2;
+#pragma unroll
+            for (int q0 = 0; q0 < NP; q0 += UB) {
+                real ul[UB], uh[UB], vl[UB], vh[UB], wl[UB], wh[UB], wc[UB];
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int idx = threadIdx.x + (q0 + q) * blockDim.x;
+                    if (idx < pln) {
+                        ul[q] = ulo[idx]; uh[q] = uhi[idx]; vl[q] = vlo[idx]; vh[q] = vhi[idx];
+                        if (low) { wl[q] = wlo[idx]; wh[q] = whi[idx]; }
+                        if (jct) wc[q] = wj[idx];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < UB; ++q) {
+                    const int idx = threadIdx.x + (q0 + q) * blockDim.x;
+                    if (idx < pln) {
+                        const int j = idx / nx, i = idx - j * nx;
+                        const int w_ = j * nxp + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nxp + i;
+                        const real2 c = A[j * nxp + i], pw = A[w_], ps = A[s_];
+                        // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
+                        ulo[idx] = ul[q] - (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] = uh[q] - (c.y * sc - pw.y * sc) * g.rdx * dts;
+                        vlo[idx] = vl[q] - (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] = vh[q] - (c.y * sc - ps.y * sc) * g.rdy * dts;
+                        const real2 cn = make_real2(c.x * sc, c.y * sc), pv = prev[q0 + q];
+                        if (low) { wlo[idx] = wl[q] - (cn.x - pv.x) * g.rdz * dts; whi[idx] = wh[q] - (pv.y - cn.y) * g.rdz * dts; }
+                        if (jct) wj[idx] = wc[q] - (cn.y - cn.x) * g.rdz * dts;
+                        prev[q0 + q] = cn;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int idx = threadIdx.x + q * blockDim.x;
+                if (idx < pln) { const int j = idx / nx; const real2 c = A[idx + j * (nxp - nx)]; prev[q] = make_real2(c.x * sc, c.y * sc); }
+            }
+        }
+        __syncthreads();                                          // A is overwritten by the next pair's spectrum
+    }
+}
+
 // vertical half of pressure_correct_velocities!: w -= dts dphi/dz on the interior faces (thread per cell, k >= 1)
 __global__ void k3_correct_w(Geo3 g, real *st, const real *phi, real dts, int B, const uint8_t *mask)
 {

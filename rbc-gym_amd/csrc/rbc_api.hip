@@ -167,6 +167,10 @@ rbc::Params2D base_params(const rbc_handle *h)
     p.min_b = h->cfg.min_b; p.delta_b = h->cfg.delta_b;
     p.heater_limit = h->cfg.heater_limit; p.kick = h->cfg.random_kick;
     p.dt = h->cfg.dt_solver; p.dt_last = h->dt_last; p.nsub = h->nsub;
+    // float copies for the packed float32 kernel (scalar kernel arguments instead of in-kernel conversions, rbc2d_kernel.hpp Params2D)
+    p.f_dx = (float)p.dx; p.f_dz = (float)p.dz; p.f_rdx = (float)p.rdx; p.f_rdz = (float)p.rdz; p.f_rdx2 = (float)p.rdx2; p.f_rdz2 = (float)p.rdz2;
+    p.f_rhz = (float)p.rhz; p.f_min_b = (float)p.min_b; p.f_dt = (float)p.dt; p.f_dt_last = (float)p.dt_last;
+    p.f_cpf = (p.f_rdz * p.f_rdz) * (float)h->nx;
     p.batch = h->B;
     p.heaters = h->cfg.heaters;
     p.mode = rbc::MODE_STEP;
@@ -581,7 +585,7 @@ int rbc_step_dev(rbc_handle *h, const float *actions_dev)
             else {
                 rbc::Params2D p = base_params(h);
                 p.actions = actions_dev;
-                p.nsub = 1; p.dt_last = h->cfg.dt_solver;
+                p.nsub = 1; p.dt_last = h->cfg.dt_solver; p.f_dt_last = (float)p.dt_last;
                 p.mask = h->d_mask;
                 if (int rc = launch(h, p, false)) return rc;
             }
@@ -949,8 +953,8 @@ int rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt)
     rbc::Params2D p = base_params(h);
     p.actions = h->d_actions;
     p.nsub = nsub;
-    p.dt = dt;
-    p.dt_last = dt;
+    p.dt = dt; p.f_dt = (float)dt;
+    p.dt_last = dt; p.f_dt_last = (float)dt;
     if (int rc = launch(h, p, false)) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RBC_OK;

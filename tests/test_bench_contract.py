@@ -125,7 +125,7 @@ def test_extra_keys_are_measured_in_the_same_run():
     sc = x["steady_ckpt"]                                   # the reference's stored steady states stay put under zero action
     assert sc["nan_envs"] == 0 and abs(sc["kinetic_energy"] / sc["reference_kinetic_energy"] - 1) < 1e-4 and sc["max_rel_ke_drift_per_env_step"] < 1e-4
     s2 = x["streaming_2d_128x64"]                           # a grid without an LDS-resident kernel: the streaming 2D path
-    assert s2["nan_envs"] == 0 and s2["value"] > 0 and 0.0 < s2["mean_nusselt_state"] < 6.0
+    assert s2["nan_envs"] == 0 and s2["value"] > 0 and s2["steps"] >= 10 and 0.0 < s2["mean_nusselt_state"] < 12.0
 
 
 def test_cpu_baseline_reports_the_compute_it_actually_got():

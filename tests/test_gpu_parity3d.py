@@ -603,6 +603,35 @@ def test_env_groups_on_separate_streams_change_nothing(native, monkeypatch):
     assert len({float(x) for x in outs[0][1]}) == B             # 16 different envs, not copies
 
 
+def test_marching_inverse_fft_is_bitwise_the_separate_vertical_correction(native, monkeypatch):
+    """k3_ifft_march (float64 default since round 4: the inverse-FFT workgroup walks two adjacent mirror-packed slab pairs, keeps
+    the previous pair's potential at its own columns in registers and applies w -= dts dphi/dz itself) against k3_ifft_pair +
+    k3_correct_w (RBC_IFFT_MARCH=0): the same expressions on the same operands in the same order, so the state is the same BIT
+    FOR BIT -- random reset (the masked projection of set!), three actuated env-steps with a clipped last substep, a masked
+    reset in between; on configs[4]'s grid (6 columns per thread), the registry default (16 x 32 x 32: nz/2 = 8, 4 columns) and
+    the flow-statistics grid (64 x 64: 8 columns per thread); float32 through the switch as well (its default is the separate pass)."""
+    for B, shape, prec in ((8, (32, 48, 48), "f64"), (3, (16, 32, 32), "f64"), (2, (32, 64, 64), "f64"), (4, (32, 48, 48), "f32")):
+        act = np.random.default_rng(B).uniform(-1, 1, (3, B, 8, 8)).astype(np.float32)
+        outs = []
+        for flag in ("0", "2"):
+            monkeypatch.setenv("RBC_IFFT_MARCH", flag)
+            sim = native.NativeSim3D(batch=B, shape=shape, ra=9000.0, dt_control=0.035, dt_solver=0.01, random_kick=0.2, precision=prec)
+            sim.reset(np.arange(7, 7 + B, dtype=np.uint64))
+            f0 = sim.get_fields()
+            assert sim.step(act[0]) and sim.step(act[1])
+            mask = np.zeros(B, np.uint8); mask[B - 1] = 1
+            sim.reset(np.arange(70, 70 + B, dtype=np.uint64), mask=mask)
+            assert sim.step(act[2])
+            outs.append((f0, sim.get_fields(), sim.get_nusselt(), sim.get_state()))
+            sim.close()
+        monkeypatch.delenv("RBC_IFFT_MARCH")
+        for x, y in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+            assert np.array_equal(x, y), (shape, prec)
+        assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+        b, u, v, w = outs[1][1]
+        assert np.all(w[:, 0] == 0) and np.all(w[:, -1] == 0) and np.isfinite(w).all()
+
+
 def test_constant_grid_instantiations_agree_with_the_generic_ones(native, monkeypatch):
     """configs[4]'s 48 x 48 planes run tile kernels instantiated with nx, ny as compile-time constants (index arithmetic by
     multiplication); RBC_NO_CONST_GRID=1 selects the generic instantiations of the same bodies.  B = 8 takes the 16 x 16 tiles,

@@ -19,23 +19,33 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.p
 BOUNDS = {
     # LDS-resident 2D kernels: one 12-wave workgroup per CU -> 168 VGPRs is the cap for 3 waves per SIMD
     # (the production instantiations: DBG = false, no MODE_TENDENCY hook)
-    "rbc::rbc2d_kernel<96, 64, double, false>": (168, 0, 43, 0),             # no scratch at all since round 3
-    "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 20, 85, 44),
+    "rbc::rbc2d_kernel<96, 64, double, false>": (168, 0, 48, 0),             # no scratch at all since round 3
+    # packed float32 pairs: 20 -> 9 spilled VGPRs in round 4 (uniform constants as float kernel arguments, nu / kappa pairs in LDS), and
+    # -- what matters -- no scratch access inside the stage loop any more: the 32 bytes left are touched in the output epilogue only
+    "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 9, 96, 32),
     # 3D tendency tiles, configs[4]'s 48 x 48 planes as compile-time constants (12 waves, 3 per SIMD).  NO spill: a reload from
     # scratch shares vmcnt with the planes prefetched one level ahead and waits for them -- six spilled VGPRs cost 7 % of the
     # env-step rate until round 3 (scripts/tile_stamps.py)
-    "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 48, 48, false>": (168, 0, 0, 0),
-    "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 32, 32, false>": (168, 0, 0, 0),
-    "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 0, 0, false>": (168, 0, 0, 0),
-    "rbc3f::k3_tile_all<16, 16, 2, 768, 3, 64, false, 48, 48, false>": (168, 0, 0, 0),
-    "rbc3::k3_tile_all<16, 4, 2, 768, 3, 64, false, 48, 48, false>": (168, 0, 0, 0),
+    "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),
+    "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 32, 32>": (168, 0, 0, 0),
+    "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 0, 0>": (168, 0, 0, 0),
+    "rbc3f::k3_tile_all<16, 16, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),
+    "rbc3::k3_tile_all<16, 4, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),
     # streaming-2D: FLAT tiles and the one-kernel projection at 128 x 64 (N1 = 16, two workgroups per CU)
-    "rbc3::k3_tile_all<1, 16, 1, 256, 3, 256, true, 0, 0, false>": (128, 0, 0, 0),
+    "rbc3::k3_tile_all<1, 16, 1, 256, 3, 256, true, 0, 0>": (128, 0, 0, 0),
     "rbc3::k2s_project_fused<16>": (104, 0, 0, 0),
     # projection kernels of the 3D path
     "rbc3::k3_rhs_fft_pair": (64, 0, 0, 0),
     "rbc3::k3_ifft_pair": (72, 0, 0, 0),
     "rbc3::k3_thomas_pair_fused<16>": (256, 0, 0, 0),
+    # inverse FFT + the whole correction (round 4, float64 default at configs[4]: 6 columns per thread): two 6-wave workgroups per
+    # CU need <= 168 VGPRs; its spilled SGPRs live in VGPR lanes, not in memory
+    "rbc3::k3_ifft_march<2, 6>": (168, 0, 64, 0),
+    "rbc3::k3_ifft_march<2, 4>": (168, 0, 64, 0),
+    # generic two-factor DFT row kernels of the streaming-2D mode (grids like 100 x 40 whose nx is not 8 * {4 ... 32}): today's
+    # numbers, scratch included -- a rarely taken path, pinned so that it does not get worse unnoticed
+    "rbc3::k2s_rhs_fft_pair": (168, 0, 0, 216),
+    "rbc3::k2s_ifft_pair": (168, 0, 0, 216),
 }
 
 
