@@ -264,15 +264,24 @@ int create3d(rbc_handle *h)
     // 3D, mirror-packed path, float64: the inverse FFT marches 2 adjacent slab pairs per workgroup and applies the vertical correction
     // itself (k3_ifft_march).  Measured at configs[4], three interleaved repeats on one box (scripts/ab_march.sh): float64 6.28k ->
     // 6.69k env-steps/s (+6.6 %; 1 pair per workgroup, i.e. every pair transformed twice: +5.3 %; 4 pairs: -3 %; 8: -21 % -- the
-    // workgroups are latency-bound, a longer serial chain costs more than the saved transforms); float32 9.36k -> 9.10k (-2.8 %; 1
-    // pair: -1.2 %), so float32 keeps k3_ifft_pair + k3_correct_w.  RBC_IFFT_MARCH=0 | 2 overrides (0: the A/B partner, bitwise the
-    // same state; also what the streaming-2D grids run).
-    if (!h->stream2d && c.nz % 4 == 0 && !h->no_pair && (size_t)c.nx * ny <= (size_t)8 * s->fft_threads) {
+    // workgroups are latency-bound, a longer serial chain costs more than the saved transforms); with everything a pair's correction
+    // reads prefetched before its transform (two waves per SIMD, 247 VGPRs): 6.31k -> 6.74k (+6.8 %; 1 pair +5.3 %, 4 pairs +0.4 %).
+    // float32: 9.36k -> 9.10k (-2.8 %), with the prefetch 9.37k -> 9.31k (-0.6 %): keeps k3_ifft_pair + k3_correct_w.  float64 planes
+    // beyond 6 columns per thread (64 x 64) keep the separate pass too (the prefetch does not fit 256 registers).
+    // RBC_IFFT_MARCH=0 | 2 overrides (0: the A/B partner, bitwise the same state; also what the streaming-2D grids run).
+    if (!h->stream2d && c.nz % 4 == 0 && !h->no_pair && (size_t)c.nx * ny <= (size_t)(std::is_same<real, double>::value ? 6 : 8) * s->fft_threads) {
         int m = std::is_same<real, double>::value ? 2 : 0;
         if (const char *e = std::getenv("RBC_IFFT_MARCH")) m = std::atoi(e);
         s->march = (m == 2) ? 2 : 0;
+#if RBC_EXPERIMENTS
+        if ((m == 1 || m == 4) && (c.nz / 2) % m == 0) s->march = m;
+#endif
     }
-    RBC_LDS_ATTR((K3::k3_ifft_march<2, 4>)); RBC_LDS_ATTR((K3::k3_ifft_march<2, 6>)); RBC_LDS_ATTR((K3::k3_ifft_march<2, 8>));
+    RBC_LDS_ATTR((K3::k3_ifft_march<2, 4>)); RBC_LDS_ATTR((K3::k3_ifft_march<2, 6>));
+    if constexpr (!std::is_same<real, double>::value) RBC_LDS_ATTR((K3::k3_ifft_march<2, 8>));
+#if RBC_EXPERIMENTS
+    RBC_LDS_ATTR((K3::k3_ifft_march<1, 6>)); RBC_LDS_ATTR((K3::k3_ifft_march<4, 6>));
+#endif
     RBC_LDS_ATTR(K3::k3_rhs_fft);
     RBC_LDS_ATTR(K3::k3_ifft);
     RBC_LDS_ATTR(K3::k3_rhs_fft_pair);
@@ -350,10 +359,14 @@ int project3d(rbc_handle *h, const rbc3_grp &q, int which, double dts, const uin
         else
         if (s->rows2d) hipLaunchKernelGGL(K3::k2s_ifft_pair, dim3(B * (g.nz / 2 / s->rows2d)), dim3(thr2d), s->fft2d_lds, q.st, g, s->plan, spec, phi, buf, dts, mk, s->rows2d);
         else if (s->march) {            // inverse FFT + the WHOLE correction, two slab pairs per workgroup: no k3_correct_w, no phi
-            const dim3 gr(B * (g.nz / 4));
+            const dim3 gr(B * (g.nz / 2 / s->march));
             const int np = (int)((pln + s->fft_threads - 1) / s->fft_threads);        // columns per thread: 4, 6 or 8
 #define RBC_MARCH(CH_, NP_) hipLaunchKernelGGL((K3::k3_ifft_march<CH_, NP_>), gr, dim3(s->fft_threads), s->fft_lds, q.st, g, s->plan, spec, buf, dts, mk)
-            if (np <= 4) RBC_MARCH(2, 4); else if (np <= 6) RBC_MARCH(2, 6); else RBC_MARCH(2, 8);
+#if RBC_EXPERIMENTS      /* chunk-length sweep (scripts/ab_march.sh with an -DRBC_EXPERIMENTS=1 library): 1 or 4 pairs per workgroup, configs[4]-sized planes only */
+            if (s->march == 1 && np <= 6) RBC_MARCH(1, 6); else if (s->march == 4 && np <= 6) RBC_MARCH(4, 6); else
+#endif
+            if (np <= 4) RBC_MARCH(2, 4); else if (np <= 6) RBC_MARCH(2, 6);
+            else if constexpr (!std::is_same<real, double>::value) RBC_MARCH(2, 8);      // (float64: 8 columns per thread do not fit the registers, create3d)
 #undef RBC_MARCH
             HIP3(hipGetLastError());
             return RBC_OK;

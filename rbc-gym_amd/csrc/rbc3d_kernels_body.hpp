@@ -1346,8 +1346,10 @@ __global__ void k3_ifft_pair(Geo3 g, FftPlan pl, const real2 *spec, real *phi, r
 // Timing bound measured before this kernel existed (a build that simply skips k3_correct_w, wrong numerics): +8.3 % float64,
 // +6.3 % float32 at configs[4]; realised with CH = 2: +6.6 % float64 (rbc3d_host_body.hpp, create3d, has the sweep over CH).
 template <int CH, int NP>                                        // NP: columns a thread owns, pln <= NP * blockDim (chosen by the host)
-__global__ void __launch_bounds__(512, 3) k3_ifft_march(Geo3 g, FftPlan pl, const real2 *spec, real *st, real dts, const uint8_t *mask)
+__global__ void __launch_bounds__(512, 2) k3_ifft_march(Geo3 g, FftPlan pl, const real2 *spec, real *st, real dts, const uint8_t *mask)
 {
+    // (two waves per SIMD, up to 256 VGPRs: a launch has B * nz / 4 workgroups -- 64 per env group at configs[4] -- so residency is no
+    //  constraint, and the registers buy the prefetch of EVERYTHING a pair's correction reads before its transform starts)
     extern __shared__ __attribute__((aligned(16))) real2 sm[];
     const int nx = g.nx, ny = g.ny, nz = g.nz, pln = nx * ny, half = nz / 2, nchunk = half / CH;
     const int env = blockIdx.x / nchunk, k0 = (blockIdx.x - env * nchunk) * CH;
@@ -1381,41 +1383,49 @@ __global__ void __launch_bounds__(512, 3) k3_ifft_march(Geo3 g, FftPlan pl, cons
 #pragma unroll
             for (int q = 0; q < NP; ++q) { const int idx = threadIdx.x + q * blockDim.x; if (idx < pln) nxt[q] = in[idx]; }
         }
+        real *ulo = ub + (size_t)p * pln, *uhi = ub + (size_t)pm * pln, *vlo = vb + (size_t)p * pln, *vhi = vb + (size_t)pm * pln;
+        real *wlo = wb + (size_t)p * pln, *whi = wb + (size_t)(nz - p) * pln, *wj = wb + (size_t)half * pln;      // faces p, nz - p, nz/2
+        const bool low = (p > 0), jct = (p == half - 1);          // the wall faces 0 and nz carry no correction
+        // ... and so does everything this pair's correction will read: u, v of both slabs, w of its two (three) faces
+        constexpr int PF = NP;      // (float64 with 8 columns per thread -- 64 x 64 planes -- does not fit 256 registers this way: the host keeps the separate pass there)
+        real ul[NP], uh[NP], vl[NP], vh[NP], wl[NP], wh[NP], wc[NP];
+        if (s >= 0) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int idx = threadIdx.x + q * blockDim.x;
+                if (idx < pln) {
+                    ul[q] = ulo[idx]; uh[q] = uhi[idx]; vl[q] = vlo[idx]; vh[q] = vhi[idx];
+                    if (low) { wl[q] = wlo[idx]; wh[q] = whi[idx]; }
+                    if (jct) wc[q] = wj[idx];
+                }
+            }
+        }
         __syncthreads();
         slab_fft2d(A, T, nx, ny, pl, twx, twy, +1);
         if (s >= 0) {
-            real *ulo = ub + (size_t)p * pln, *uhi = ub + (size_t)pm * pln, *vlo = vb + (size_t)p * pln, *vhi = vb + (size_t)pm * pln;
-            real *wlo = wb + (size_t)p * pln, *whi = wb + (size_t)(nz - p) * pln, *wj = wb + (size_t)half * pln;      // faces p, nz - p, nz/2
-            const bool low = (p > 0), jct = (p == half - 1);      // the wall faces 0 and nz carry no correction
-            // all global loads of a batch first (six waves have little else to hide their latency), then the updates
-            constexpr int UB = 2;
 #pragma unroll
-            for (int q0 = 0; q0 < NP; q0 += UB) {
-                real ul[UB], uh[UB], vl[UB], vh[UB], wl[UB], wh[UB], wc[UB];
-#pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int idx = threadIdx.x + (q0 + q) * blockDim.x;
-                    if (idx < pln) {
-                        ul[q] = ulo[idx]; uh[q] = uhi[idx]; vl[q] = vlo[idx]; vh[q] = vhi[idx];
-                        if (low) { wl[q] = wlo[idx]; wh[q] = whi[idx]; }
-                        if (jct) wc[q] = wj[idx];
-                    }
+            for (int q = PF; q < NP; ++q) {
+                const int idx = threadIdx.x + q * blockDim.x;
+                if (idx < pln) {
+                    ul[q] = ulo[idx]; uh[q] = uhi[idx]; vl[q] = vlo[idx]; vh[q] = vhi[idx];
+                    if (low) { wl[q] = wlo[idx]; wh[q] = whi[idx]; }
+                    if (jct) wc[q] = wj[idx];
                 }
+            }
 #pragma unroll
-                for (int q = 0; q < UB; ++q) {
-                    const int idx = threadIdx.x + (q0 + q) * blockDim.x;
-                    if (idx < pln) {
-                        const int j = idx / nx, i = idx - j * nx;
-                        const int w_ = j * nxp + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nxp + i;
-                        const real2 c = A[j * nxp + i], pw = A[w_], ps = A[s_];
-                        // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
-                        ulo[idx] = ul[q] - (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] = uh[q] - (c.y * sc - pw.y * sc) * g.rdx * dts;
-                        vlo[idx] = vl[q] - (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] = vh[q] - (c.y * sc - ps.y * sc) * g.rdy * dts;
-                        const real2 cn = make_real2(c.x * sc, c.y * sc), pv = prev[q0 + q];
-                        if (low) { wlo[idx] = wl[q] - (cn.x - pv.x) * g.rdz * dts; whi[idx] = wh[q] - (pv.y - cn.y) * g.rdz * dts; }
-                        if (jct) wj[idx] = wc[q] - (cn.y - cn.x) * g.rdz * dts;
-                        prev[q0 + q] = cn;
-                    }
+            for (int q = 0; q < NP; ++q) {
+                const int idx = threadIdx.x + q * blockDim.x;
+                if (idx < pln) {
+                    const int j = idx / nx, i = idx - j * nx;
+                    const int w_ = j * nxp + ((i == 0) ? nx - 1 : i - 1), s_ = ((j == 0) ? ny - 1 : j - 1) * nxp + i;
+                    const real2 c = A[j * nxp + i], pw = A[w_], ps = A[s_];
+                    // same operation order as k3_correct: (phi_c - phi_w) * rdx * dts on the normalised potentials
+                    ulo[idx] = ul[q] - (c.x * sc - pw.x * sc) * g.rdx * dts; uhi[idx] = uh[q] - (c.y * sc - pw.y * sc) * g.rdx * dts;
+                    vlo[idx] = vl[q] - (c.x * sc - ps.x * sc) * g.rdy * dts; vhi[idx] = vh[q] - (c.y * sc - ps.y * sc) * g.rdy * dts;
+                    const real2 cn = make_real2(c.x * sc, c.y * sc), pv = prev[q];
+                    if (low) { wlo[idx] = wl[q] - (cn.x - pv.x) * g.rdz * dts; whi[idx] = wh[q] - (pv.y - cn.y) * g.rdz * dts; }
+                    if (jct) wj[idx] = wc[q] - (cn.y - cn.x) * g.rdz * dts;
+                    prev[q] = cn;
                 }
             }
         } else {

@@ -1,0 +1,3 @@
+for i in 1 2 3; do
+  for m in 1 2 4; do for p in f64 f32; do echo -n "march=$m "; RBC_HIP_LIB=build/librbc_hip_exp.so RBC_IFFT_MARCH=$m python scripts/rate_3d.py $p 2>&1 | grep -v amdgpu.ids; done; done
+done

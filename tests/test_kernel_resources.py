@@ -38,10 +38,11 @@ BOUNDS = {
     "rbc3::k3_rhs_fft_pair": (64, 0, 0, 0),
     "rbc3::k3_ifft_pair": (72, 0, 0, 0),
     "rbc3::k3_thomas_pair_fused<16>": (256, 0, 0, 0),
-    # inverse FFT + the whole correction (round 4, float64 default at configs[4]: 6 columns per thread): two 6-wave workgroups per
-    # CU need <= 168 VGPRs; its spilled SGPRs live in VGPR lanes, not in memory
-    "rbc3::k3_ifft_march<2, 6>": (168, 0, 64, 0),
-    "rbc3::k3_ifft_march<2, 4>": (168, 0, 64, 0),
+    # inverse FFT + the whole correction (round 4, float64 default at configs[4]: 6 columns per thread): compiled for two waves per
+    # SIMD -- a launch has 64 workgroups per env group, residency is no constraint -- so that everything a pair's correction reads is
+    # prefetched before its transform; no spill to memory (its spilled SGPRs live in VGPR lanes)
+    "rbc3::k3_ifft_march<2, 6>": (256, 0, 80, 0),
+    "rbc3::k3_ifft_march<2, 4>": (256, 0, 80, 0),
     # generic two-factor DFT row kernels of the streaming-2D mode (grids like 100 x 40 whose nx is not 8 * {4 ... 32}): today's
     # numbers, scratch included -- a rarely taken path, pinned so that it does not get worse unnoticed
     "rbc3::k2s_rhs_fft_pair": (168, 0, 0, 216),
