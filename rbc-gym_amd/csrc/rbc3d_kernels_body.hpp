@@ -418,6 +418,13 @@ __global__ void __launch_bounds__(128) k3_tend_march(Geo3 g, const real *cur, re
 // are never read again (zeta^1 = 0).
 constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx <= 64): row/plane offsets become immediates
 
+// -DRBC_EXPERIMENT_HALF_FLUX=1: timing bound only (WRONG numerics, never shipped): the west / south face fluxes of every field are not
+// computed -- what sharing each horizontal face flux between the two cells it separates could save at most if the exchange were free.
+// Measured at configs[4] (NOTES.md R4): float64 +3 %, float32 +7.6 %.  Not worth an LDS exchange and a third barrier per level.
+#ifndef RBC_EXPERIMENT_HALF_FLUX
+#define RBC_EXPERIMENT_HALF_FLUX 0
+#endif
+
 // One env's [b | u | v | w] block of a state-sized buffer (state, next state or G^-) as the tile kernels address it: a UNIFORM
 // element offset (field + level, computed on the scalar unit) plus a 32-bit per-lane BYTE offset (own column, or the plane element
 // a thread stages).  BUF = false (shipped): plain pointer arithmetic; hipcc folds `base + column` into a 64-bit VGPR pair and spends
@@ -631,12 +638,20 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IU, q - 3, 0); c7[q] = (q == 3 || FLAT) ? f0 : L(IU, 0, q - 3); }
             const real fe = upw5<real>(sym4(q7[2], q7[3], q7[4], q7[5]), q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+            const real fw = fe * real(0.5);      /* timing bound only, WRONG numerics */
+#else
             const real fw = upw5<real>(sym4(q7[1], q7[2], q7[3], q7[4]), q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
+#endif
             real on_m = real(0.0), on_c = real(0.0), os_m = real(0.0), os_c = real(0.0), fn = real(0.0), fs = real(0.0);      // FLAT: v == 0, no y fluxes
             if constexpr (!FLAT) {
                 on_m = L(IV, -1, 1); on_c = L(IV, 0, 1); os_m = L(IV, -1, 0); os_c = winv[2];
                 fn = upw5<real>(sym4(L(IV, -2, 1), on_m, on_c, L(IV, 1, 1)), c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+                fs = fn * real(0.5);
+#else
                 fs = upw5<real>(sym4(L(IV, -2, 0), os_m, os_c, L(IV, 1, 0)), c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
+#endif
             }
             real ft = real(0.0), dwt = real(0.0), fup;
             if (!top) {
@@ -663,10 +678,18 @@ __device__ __forceinline__ void tile_uv_body(const Geo3 &g, const real *cur, rea
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? f0 : L(IV, 0, q - 3); c7[q] = (q == 3) ? f0 : L(IV, q - 3, 0); }
             const real fe = upw5<real>(sym4(q7[2], q7[3], q7[4], q7[5]), q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+            const real fw = fe * real(0.5);      /* timing bound only, WRONG numerics */
+#else
             const real fw = upw5<real>(sym4(q7[1], q7[2], q7[3], q7[4]), q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
+#endif
             const real on_m = L(IU, 1, -1), on_c = L(IU, 1, 0), os_m = L(IU, 0, -1), os_c = winu[2];
             const real fn = upw5<real>(sym4(L(IU, 1, -2), on_m, on_c, L(IU, 1, 1)), c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+            const real fs = fn * real(0.5);
+#else
             const real fs = upw5<real>(sym4(L(IU, 0, -2), os_m, os_c, L(IU, 0, 1)), c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
+#endif
             real ft = real(0.0), dwt = real(0.0), fup;
             if (!top) {
                 const real wm = L(IW, 0, -1);
@@ -785,11 +808,19 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? w0 : L(IW, q - 3, 0); c7[q] = (q == 3 || FLAT) ? w0 : L(IW, 0, q - 3); }
                 const real fe = upw5<real>(zfS4(eu, k, nz), q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+            const real fw = fe * real(0.5);      /* timing bound only, WRONG numerics */
+#else
                 const real fw = upw5<real>(zfS4(au, k, nz), q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
+#endif
                 real fn = real(0.0), fs = real(0.0);
                 if constexpr (!FLAT) {
                     fn = upw5<real>(zfS4(ev, k, nz), c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+                fs = fn * real(0.5);
+#else
                     fs = upw5<real>(zfS4(av, k, nz), c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
+#endif
                 }
                 const real adv = (fe - fw) * rdx + (fn - fs) * rdy + (ft - fbw) * rdz;
                 const real vis = nu * ((((eu[2] - eu[1]) * rdz + (q7[4] - w0) * rdx) - ((au[2] - au[1]) * rdz + (w0 - q7[2]) * rdx)) * rdx
@@ -810,11 +841,19 @@ __device__ __forceinline__ void tile_wb_body(const Geo3 &g, const real *cur, rea
 #pragma unroll
             for (int q = 0; q < 7; ++q) { q7[q] = (q == 3) ? b0 : L(IB, q - 3, 0); c7[q] = (q == 3 || FLAT) ? b0 : L(IB, 0, q - 3); }
             const real fe = upw5<real>(eu[2], q7[1], q7[2], q7[3], q7[4], q7[5], q7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+            const real fw = fe * real(0.5);      /* timing bound only, WRONG numerics */
+#else
             const real fw = upw5<real>(au[2], q7[0], q7[1], q7[2], q7[3], q7[4], q7[5]);
+#endif
             real fn = real(0.0), fs = real(0.0);
             if constexpr (!FLAT) {
                 fn = upw5<real>(ev[2], c7[1], c7[2], c7[3], c7[4], c7[5], c7[6]);
+#if RBC_EXPERIMENT_HALF_FLUX
+                fs = fn * real(0.5);
+#else
                 fs = upw5<real>(av[2], c7[0], c7[1], c7[2], c7[3], c7[4], c7[5]);
+#endif
             }
             real ft = real(0.0), bup;
             if (k + 1 < nz) { ft = upw(winw[3], zfL(winb, k + 1, nz), zfR(winb, k + 1, nz)); bup = winb[3]; }
