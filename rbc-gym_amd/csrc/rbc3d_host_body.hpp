@@ -462,7 +462,12 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
     const bool no_nxc = [] { const char *e = std::getenv("RBC_NO_CONST_GRID"); return e && e[0] == '1'; }();      // A/B: the generic instantiations
     int shape = 0;
     auto wgs = [&](int ty, int kt) { return 2 * B * (g.ny / ty) * (g.nz / kt); };       // workgroups of one launch
-    if (want("16x16", wgs(16, 16) >= 96) && tiles_fit(16, 16, 768)) shape = 1;
+    // float32: the tall tiles only once a launch has ~two hundred workgroups.  With four chains in flight a 96-workgroup launch per chain
+    // is 384 workgroups on 256 CUs -- a round and a half -- and the half-empty second round costs the float32 kernel (shorter levels,
+    // more issue-bound) more than the extra chunk prologues of 16 x 8 tiles: configs[4] float32 9.37k -> 9.94k env-steps/s (+6 %;
+    // float64 prefers the tall tiles: 6.66k against 6.40k).  B = 64: 16 x 16 again (192 workgroups per launch), 10.8k.
+    const int tall_min = std::is_same<real, float>::value ? 192 : 96;
+    if (want("16x16", wgs(16, 16) >= tall_min) && tiles_fit(16, 16, 768)) shape = 1;
     else if (want("16x8", wgs(16, 8) >= 96) && tiles_fit(16, 8, 768)) shape = 2;
     else if (want("16x4", true) && tiles_fit(16, 4, 768)) shape = 3;
     else if (want("8x8", true) && tiles_fit(8, 8, 512)) shape = 4;

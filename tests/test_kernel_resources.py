@@ -31,6 +31,7 @@ BOUNDS = {
     "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 0, 0>": (168, 0, 0, 0),
     "rbc3f::k3_tile_all<16, 16, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),
     "rbc3::k3_tile_all<16, 4, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),
+    "rbc3f::k3_tile_all<16, 8, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),      # what configs[4] runs in float32 since round 4 (B = 32: 16 x 8 tiles)
     # streaming-2D: FLAT tiles and the one-kernel projection at 128 x 64 (N1 = 16, two workgroups per CU)
     "rbc3::k3_tile_all<1, 16, 1, 256, 3, 256, true, 0, 0>": (128, 0, 0, 0),
     "rbc3::k2s_project_fused<16>": (104, 0, 0, 0),
