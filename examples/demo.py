@@ -6,7 +6,8 @@
     python examples/demo.py vector [envs] [steps]   gym.make_vec -> ONE device-batched env (6 or 6000 envs alike)
     python examples/demo.py wrapped [steps]         observation / reward normalisation + reward shaping wrappers
     python examples/demo.py checkpoint [file] [steps]   episodes from converged states (generated on the GPU if absent)
-    python examples/demo.py three-d [time] [f32]    the 3D env (f32: the float32 instantiation of the 3D kernels, 1.5x at configs[4])
+    python examples/demo.py three-d [time] [f32] [recorded]   the 3D env (f32: the float32 instantiation of the 3D kernels; recorded: the
+                                                    solver-step count of the reference's recorded flowstats series)
     python examples/demo.py timing [iterations]     construction / reset / step latency of one env
 """
 import os
@@ -99,8 +100,10 @@ def checkpoint(args):
 
 def three_d(args):
     precision = "f32" if "f32" in args else "f64"
-    args = [a for a in args if a != "f32"]
-    env = gym.make(ENV3D, rayleigh_number=2500, heater_duration=0.25, episode_length=_int(args, 0, 50), precision=precision)
+    clock = "recorded" if "recorded" in args else "documented"
+    args = [a for a in args if a not in ("f32", "recorded")]
+    env = gym.make(ENV3D, rayleigh_number=2500, heater_duration=0.25, episode_length=_int(args, 0, 50), precision=precision,
+                   reference_clock=clock)
     obs, _ = rollout(env, 10**9, zero_action, keys=("nusselt",))
     print("observation", obs.shape)
     env.close()

@@ -581,6 +581,7 @@ int rbc_step_dev(rbc_handle *h, const float *actions_dev)
             // alone -- the same arithmetic as the first substep of a full interval, nothing is carried from one RK3 substep
             // into the next (zeta^1 = 0) --, then every env runs the nsub - 1 steps of a later interval
             HIP_TRY(hipMemcpyAsync(h->d_mask, h->fresh.data(), (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));      // `fresh` is pageable and rewritten by the next call; mixed batches are rare
             if (h->s3) { if (int rc = RBC_S3(h, lead_substep3d, h, actions_dev, h->d_mask)) return rc; }
             else {
                 rbc::Params2D p = base_params(h);
