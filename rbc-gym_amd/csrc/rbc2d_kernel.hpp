@@ -1396,6 +1396,11 @@ dbl2 *pk = park(1);
     scal *sscr = reinterpret_cast<scal *>(scr);          // reductions run per lane on scalars
     // the lane -> env map is re-derived here from an opaque copy of the workgroup index: kept alive across the stage loop it
     // costs scalar registers that hipcc then spills into VGPR lanes (v_readlane in the hot passes: +6 % on the f64 kernel)
+    // The final u, w, b are in LDS as well as in registers: this block reads them from LDS, so that the three 8-row arrays of pairs
+    // are dead before it starts (with them alive across both lanes' output code hipcc spilled nine VGPRs here)
+    auto FB_ = [&](int r) -> real { return lds[(k0 + r) * RS + FB + i]; };
+    auto FU_ = [&](int r) -> real { return lds[(k0 + r) * RS + FU + i]; };
+    auto FW_ = [&](int r) -> real { return lds[(k0 + r) * RS + FW + i]; };
     int wg_o = blockIdx.x;
     asm volatile("" : "+s"(wg_o));
 #pragma unroll
@@ -1410,9 +1415,9 @@ dbl2 *pk = park(1);
 #pragma unroll
             for (int r = 0; r < CZ; ++r) {
                 const int k = k0 + r;
-                gb_[k * NX + i] = (double)lane(bn[r], e);
-                gu_[k * NX + i] = (double)lane(un[r], e);
-                gw_[k * NX + i] = (double)lane(wn[r], e);
+                gb_[k * NX + i] = (double)lane(FB_(r), e);
+                gu_[k * NX + i] = (double)lane(FU_(r), e);
+                gw_[k * NX + i] = (double)lane(FW_(r), e);
             }
             if (top) gw_[NZ * NX + i] = 0.0;
         }
@@ -1420,7 +1425,7 @@ dbl2 *pk = park(1);
         // A13 NaN flag
         double bad = 0.0;
 #pragma unroll
-        for (int r = 0; r < CZ; ++r) bad += (isnan(lane(bn[r], e)) || isnan(lane(un[r], e)) || isnan(lane(wn[r], e))) ? 1.0 : 0.0;
+        for (int r = 0; r < CZ; ++r) bad += (isnan(lane(FB_(r), e)) || isnan(lane(FU_(r), e)) || isnan(lane(FW_(r), e))) ? 1.0 : 0.0;
         bad = block_sum<G::NT>(bad, sscr, tid);
         if (tid == 0) P.flags[env] = (bad > 0.0) ? 1 : 0;
 
@@ -1442,8 +1447,8 @@ dbl2 *pk = park(1);
                 const int k = k0 + r;
                 if (xs && (k % stz) == 0) {
                     const size_t o = (size_t)(k / stz) * P.obs_nx + (i / stx);
-                    ob[o] = obs_value(P, 0, (double)lane(bn[r], e)); ob[och + o] = obs_value(P, 1, (double)lane(un[r], e));
-                    ob[2 * och + o] = obs_value(P, 2, (double)lane(wn[r], e));
+                    ob[o] = obs_value(P, 0, (double)lane(FB_(r), e)); ob[och + o] = obs_value(P, 1, (double)lane(FU_(r), e));
+                    ob[2 * och + o] = obs_value(P, 2, (double)lane(FW_(r), e));
                     ob[3 * och + o] = obs_value(P, 3, (double)lane(phy[r], e)); ob[4 * och + o] = obs_value(P, 4, (double)(lane(ph[r], e) - pmean));
                 }
             }
@@ -1452,7 +1457,7 @@ dbl2 *pk = park(1);
 #pragma unroll
                 for (int r = 0; r < CZ; ++r) {
                     const int o = (k0 + r) * NX + i;
-                    sb[o] = (float)lane(bn[r], e); sb[G::NCELL + o] = (float)lane(un[r], e); sb[2 * G::NCELL + o] = (float)lane(wn[r], e);
+                    sb[o] = (float)lane(FB_(r), e); sb[G::NCELL + o] = (float)lane(FU_(r), e); sb[2 * G::NCELL + o] = (float)lane(FW_(r), e);
                     sb[3 * G::NCELL + o] = (float)lane(phy[r], e); sb[4 * G::NCELL + o] = (float)(lane(ph[r], e) - pmean);
                 }
             }
@@ -1467,7 +1472,7 @@ dbl2 *pk = park(1);
             const bool xs = (i % stx) == 0;
 #pragma unroll
             for (int r = 0; r < CZ; ++r)
-                if (xs && ((k0 + r) % stz) == 0) q1 += (double)lane(bn[r], e) * (double)lane(wn[r], e);
+                if (xs && ((k0 + r) % stz) == 0) q1 += (double)lane(FB_(r), e) * (double)lane(FW_(r), e);
             q1 = block_sum<G::NT>(q1, sscr, tid);
             // row means of T on the (sub)grid: thread t sums segment seg of row
             __syncthreads();

@@ -20,9 +20,9 @@ BOUNDS = {
     # LDS-resident 2D kernels: one 12-wave workgroup per CU -> 168 VGPRs is the cap for 3 waves per SIMD
     # (the production instantiations: DBG = false, no MODE_TENDENCY hook)
     "rbc::rbc2d_kernel<96, 64, double, false>": (168, 0, 48, 0),             # no scratch at all since round 3
-    # packed float32 pairs: 20 -> 9 spilled VGPRs in round 4 (uniform constants as float kernel arguments, nu / kappa pairs in LDS), and
-    # -- what matters -- no scratch access inside the stage loop any more: the 32 bytes left are touched in the output epilogue only
-    "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 9, 96, 32),
+    # packed float32 pairs: 20 spilled VGPRs / 44 B scratch -> NONE in round 4 (uniform constants as float kernel arguments, nu / kappa
+    # pairs in LDS, the output block reads the final fields from LDS instead of holding three 8-row arrays of pairs across both lanes)
+    "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 0, 96, 0),
     # 3D tendency tiles, configs[4]'s 48 x 48 planes as compile-time constants (12 waves, 3 per SIMD).  NO spill: a reload from
     # scratch shares vmcnt with the planes prefetched one level ahead and waits for them -- six spilled VGPRs cost 7 % of the
     # env-step rate until round 3 (scripts/tile_stamps.py)
