@@ -173,3 +173,26 @@ def test_recorded_clock_through_the_gym_layer(native):
     assert np.array_equal(ov, od)                                   # first interval after the autoreset: full again
     assert np.array_equal(ov[0], o1)                                # ... and the single env's (seed s + 0, same action)
     venv.close(); vdoc.close()
+
+
+def test_recorded_clock_on_a_sharded_vector_env(native):
+    """devices=[0, 0]: two handles behind one env object, each with its own fresh-env bookkeeping; bitwise the single-handle env,
+    through a NEXT_STEP autoreset that restarts all envs and a later masked restart of one shard's env only"""
+    from rbc_gym.vector import RayleighBenardConvection2DVectorEnv
+    kw = dict(num_envs=5, heater_duration=0.3, episode_length=0.9, reference_clock="recorded")
+    one = RayleighBenardConvection2DVectorEnv(**kw)
+    two = RayleighBenardConvection2DVectorEnv(devices=[0, 0], **kw)
+    rng = np.random.default_rng(9)
+    one.reset(seed=21); two.reset(seed=21)
+    for n in range(6):                                             # 3 steps to truncation, the autoreset step, two more
+        a = rng.uniform(-1, 1, (5, 12)).astype(np.float32)
+        ro, rt = one.step(a), two.step(a)
+        assert np.array_equal(ro[0], rt[0]) and np.array_equal(ro[1], rt[1]) and np.array_equal(ro[3], rt[3]), n
+        assert np.array_equal(ro[4]["t"], rt[4]["t"]) and np.array_equal(ro[4]["step"], rt[4]["step"])
+    m = np.array([0, 0, 0, 1, 0], np.uint8)                        # env 3 lives on the second shard
+    for env in (one, two):
+        env._reset_envs(m)
+    a = rng.uniform(-1, 1, (5, 12)).astype(np.float32)
+    ro, rt = one.step(a), two.step(a)
+    assert np.array_equal(ro[0], rt[0]) and np.array_equal(ro[4]["step"], rt[4]["step"]) and ro[4]["step"][3] == 2
+    one.close(); two.close()
