@@ -321,6 +321,7 @@ template <> __device__ __forceinline__ f32x2 bc<f32x2>(double x) { return f32x2(
 // the same for a constant that exists in both precisions (Params2D: double for the one-env kernels, float for the packed variant)
 template <typename T> __device__ __forceinline__ T bc2(double d, float) { return (T)d; }
 template <> __device__ __forceinline__ f32x2 bc2<f32x2>(double, float f) { return f32x2(f); }
+template <> __device__ __forceinline__ float bc2<float>(double, float f) { return f; }      // one env per workgroup in float32: same reason
 __device__ __forceinline__ double lane(double x, int) { return x; }
 __device__ __forceinline__ float lane(float x, int) { return x; }
 __device__ __forceinline__ float lane(f32x2 x, int e) { return e ? x.y : x.x; }
