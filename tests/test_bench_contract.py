@@ -88,24 +88,24 @@ def test_self_launched_two_rank_rehearsal_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_self_launched_five_rank_rehearsal_on_one_gpu():
-    """SCALE readiness without a node: `--gpus 5` with no launcher -- the self-launch is decided before any GPU call, five ranks
-    (this pool lets six processes touch one card and the test runner is one of them; the eight-rank reductions run on the CPU in
-    tests/test_sharding_gloo.py::test_eight_rank_reductions_of_the_scale_line) create five handles on the one device, step their
-    shards between gloo barriers, and rank 0 prints ONE line: n_gpus 5, global batch 5 x 128, `per_rank` of length five, the CPU
-    baseline taken by the parent before the ranks existed."""
+def test_self_launched_four_rank_rehearsal_on_one_gpu():
+    """SCALE readiness without a node: `--gpus 4` with no launcher -- the self-launch is decided before any GPU call, four ranks
+    (this pool lets six processes touch one card, the test runner is one of them, and one slot is left as margin; the eight-rank
+    reductions run on the CPU in tests/test_sharding_gloo.py::test_eight_rank_reductions_of_the_scale_line) create four handles on the
+    one device, step their shards between gloo barriers, and rank 0 prints ONE line: n_gpus 4, global batch 4 x 128, `per_rank` of
+    length four, the CPU baseline taken by the parent before the ranks existed."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--dist-backend", "gloo", "--steps", "3",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dist-backend", "gloo", "--steps", "3",
                           "--warmup", "1", "--batch", "128"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 5 and d["config"]["global_batch"] == 640 and d["nan_envs"] == 0 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 512 and d["nan_envs"] == 0 and d["scaling"] == "weak"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     pr = d["per_rank"]
-    assert len(pr["ms_per_step"]) == 5 and pr["nan_envs"] == [0] * 5 and abs(max(pr["ms_per_step"]) - d["ms_per_step"]) < 1e-9
-    assert abs(d["value"] - 640 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert len(pr["ms_per_step"]) == 4 and pr["nan_envs"] == [0] * 4 and abs(max(pr["ms_per_step"]) - d["ms_per_step"]) < 1e-9
+    assert abs(d["value"] - 512 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert "extra" not in d                                   # the extras belong to the N = 1 line
 
 

@@ -96,7 +96,7 @@ def _worker8(rank, world, port, q):
 def test_eight_rank_reductions_of_the_scale_line():
     """world_size 8 over gloo on the CPU: the shards of configs[2] tile the 8192 envs, seeds run on across the shard boundaries,
     `value` would use the slowest rank, `per_rank` lists all eight.  (On the GPU box at most six processes may touch the card,
-    so the GPU rehearsal of the self-launching bench, tests/test_bench_contract.py, runs five ranks next to the test runner; the
+    so the GPU rehearsal of the self-launching bench, tests/test_bench_contract.py, runs four ranks next to the test runner; the
     eight-rank case is covered here without a GPU and by the driver on a real node.)"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
