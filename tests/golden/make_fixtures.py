@@ -147,7 +147,7 @@ def chaotic_profiles():
     episodes (train 20, val 10, test 10: independent random initial conditions at t = 600, rbc_sim2D.jl:41-43,64-66) --
     where the boundary layers are 1-2 cells thick these rows are what the near-wall advection stencils decide.  Data only."""
     for ra in (30000, 100000, 300000, 1000000, 3000000, 10000000):
-        prof, spec, kes, umeans = [], [], [], []
+        prof, spec, kes, umeans, xspec = [], [], [], [], []
         for split in ("train", "val", "test"):
             with h5py.File(f"{REF}/{split}/ckpt_ra{ra}.h5", "r") as f:
                 b = f["b"][...][:, 0]; u = f["u"][...][:, 0]; w = f["w"][...][:, 0]
@@ -157,9 +157,13 @@ def chaotic_profiles():
                 spec.append(np.abs(np.fft.rfft(w[w.shape[0] // 2, :, e]))[:9] / w.shape[1])
                 kes.append(0.5 * ((u[..., e] ** 2).mean() + (w[:-1, :, e] ** 2).mean()))
                 umeans.append(u[..., e].mean(1))                       # horizontal-mean (zonal) flow per row
+                # x power spectra averaged over the rows, |F_k|^2 / nx^2 for b', u, w (b' = b minus its row mean): where the grid-scale
+                # dissipation of the advection scheme shows (49 wavenumbers x 3 fields per episode)
+                xspec.append(np.stack([(np.abs(np.fft.rfft(f - f.mean(1, keepdims=True), axis=1)) ** 2).mean(0) / f.shape[1] ** 2
+                                       for f in (b[..., e], u[..., e], w[:-1, :, e])]))
         prof = np.array(prof)
         np.savez_compressed(f"{OUT}/ckpt2d_ra{ra}_profiles.npz", profiles=prof, moments=np.array(PROFILE_MOMENTS), ra=np.array(ra),
-                            wmid_spec=np.array(spec), ke=np.array(kes), umean=np.array(umeans))
+                            wmid_spec=np.array(spec), ke=np.array(kes), umean=np.array(umeans), xspec=np.array(xspec))
         m, se = prof.mean(0), prof.std(0, ddof=1) / np.sqrt(len(prof))
         print(f"Ra={ra}: {len(prof)} episodes; <b> rows 0..2 {np.round(m[0, :3], 4)} +- {np.round(se[0, :3], 4)}; <w^2> rows 1..3 {np.round(m[2, 1:4], 5)}")
 
