@@ -3,7 +3,7 @@
 // Replaces `step_simulation`/`initialize_simulation` of src/rbc_gym/sim/rbc_sim3D_api.jl (77-101,
 // 17-72) for a batch of envs.  A 3D env (32x48x48: 2.4 MB of fp64 state) does not fit one CU's LDS,
 // so unlike the 2D kernel the state lives in HBM/L2 and every RK3 stage is a short sequence of launches
-// (rbc3d_host.hpp: advance3d / project3d):
+// (rbc3d_host.hpp: advance3d / project3d; DESIGN.md section 3b, NOTES.md section 5b):
 //   k3_tile_all (LDS-tiled tendencies of (u,v) and (w,b), U* into the other state buffer; z-marching and
 //   cell-per-thread kernels as fallbacks for other grid shapes) -> k3_rhs_fft_pair (divergence of two mirror
 //   slabs as one complex 2D FFT in LDS) -> k3_thomas_pair_fused (z solve per (kx,ky) from both walls on the

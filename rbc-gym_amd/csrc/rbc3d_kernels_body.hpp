@@ -433,7 +433,7 @@ constexpr int NXP3 = 64;               // padded row length of an LDS plane (nx 
 // block -- `buffer_load_dwordx2 v, v_off, s[rsrc:rsrc+3], s_off offen`, NO vector instruction per access: 1 v_lshl_add_u64 left in
 // the kernel, 166 -> 141 VGPRs (float32: 130 -> 100).  Measured on one box, three interleaved repeats (scripts/ab_rate3d.sh,
 // configs[4]): float64 6.32k against 6.36k env-steps/s (noise), float32 9.16k against 9.48k (-3.4 %).  The address arithmetic was
-// never what the kernel waits for (it is bound by operand latency and the two barriers of a level); the
+// never what the kernel waits for (it is bound by operand latency and the two barriers of a level, DESIGN.md section 3b, NOTES.md section 5b); the
 // descriptor path is kept as a build flag for the record, off.
 #ifndef RBC_TILE_BUFFER_ADDR
 #define RBC_TILE_BUFFER_ADDR 0

@@ -46,7 +46,7 @@ class RayleighBenardConvection3DEnv(NativeEnvBase):
         log_dir: str = None,
         env_id: int = 0,
         device: int = 0,
-        precision: str = "f64",          # "f64": the reference's Float64 arithmetic; "f32": the float32 instantiation of the 3D kernels (DESIGN.md 5b)
+        precision: str = "f64",          # "f64": the reference's Float64 arithmetic; "f32": the float32 instantiation of the 3D kernels (DESIGN.md 3b)
         reference_clock: str = "documented",   # "recorded": the solver-step count of the reference's recorded series
     ) -> None:
         super().__init__()

@@ -25,7 +25,7 @@ BOUNDS = {
     "rbc::rbc2d_kernel<96, 64, float __vector(2), false>": (168, 0, 96, 0),
     # 3D tendency tiles, configs[4]'s 48 x 48 planes as compile-time constants (12 waves, 3 per SIMD).  NO spill: a reload from
     # scratch shares vmcnt with the planes prefetched one level ahead and waits for them -- six spilled VGPRs cost 7 % of the
-    # env-step rate until round 3 (scripts/tile_stamps.py)
+    # env-step rate until round 3 (NOTES.md section 5b, scripts/tile_stamps.py)
     "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 48, 48>": (168, 0, 0, 0),
     "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 32, 32>": (168, 0, 0, 0),
     "rbc3::k3_tile_all<16, 16, 2, 768, 3, 64, false, 0, 0>": (168, 0, 0, 0),
