@@ -90,3 +90,17 @@ def test_gym_stand_in_seeding_contract():
     assert e.np_random_seed == s0                  # reset(seed=None) never reseeds (the quirk rbc2D.py:150 relies on)
     e.reset(seed=11)
     assert e.np_random_seed == 11
+
+
+def test_reference_clock_kwarg_is_validated_before_any_device_call():
+    """`reference_clock` ("documented" | "recorded") on both env classes and both vector envs: a wrong
+    name is a ValueError whether or not a GPU is there; the two names map onto the C ABI's RBC_CLOCK_* values"""
+    from rbc_gym import _native
+    from rbc_gym.envs import RayleighBenardConvection2DEnv, RayleighBenardConvection3DEnv
+    from rbc_gym.vector import RayleighBenardConvection2DVectorEnv, RayleighBenardConvection3DVectorEnv
+    assert _native.CLOCKS == {"documented": 0, "recorded": 1} and _native.clock_code("recorded") == 1 and _native.clock_code(0) == 0
+    for make in (lambda: RayleighBenardConvection2DEnv(reference_clock="julia"), lambda: RayleighBenardConvection3DEnv(reference_clock="julia"),
+                 lambda: RayleighBenardConvection2DVectorEnv(num_envs=2, reference_clock="julia"),
+                 lambda: RayleighBenardConvection3DVectorEnv(num_envs=2, reference_clock="julia")):
+        with pytest.raises(ValueError, match="reference_clock"):
+            make()
