@@ -452,11 +452,12 @@ static void poisson_fft_tridiag(rbco_sim *s)
     for (int k = 0; k < nz; ++k)
         for (int i = 0; i < nx; ++i) {
             double a = re[k];
-            for (int m = 1; m < nh; ++m) {
+            const int even = (nx % 2 == 0);      /* odd nx: modes 1..(nx-1)/2 each with their conjugate, no Nyquist mode */
+            for (int m = 1; m < (even ? nh : nh + 1); ++m) {
                 int t = (int)(((long)m * i) % nx);
                 a += 2 * (re[m * nz + k] * s->cosx[t] - im[m * nz + k] * s->sinx[t]);
             }
-            a += re[nh * nz + k] * ((i & 1) ? -1.0 : 1.0);
+            if (even) a += re[nh * nz + k] * ((i & 1) ? -1.0 : 1.0);
             s->phi[k * nx + i] = a / nx;
         }
     free(re);

@@ -88,8 +88,10 @@ static double bottom_T3(const rbco3_sim *s, int i, int j)
     const int n = s->c.heaters;
     double x = (i + 0.5) * s->dx, y = (j + 0.5) * s->dy;
     int a = (int)floor(x / s->c.lx * n) + 1, bq = (int)floor(y / s->c.ly * n) + 1;
-    if (a < 1) a = 1; if (a > n) a = n;
-    if (bq < 1) bq = 1; if (bq > n) bq = n;
+    if (a < 1) a = 1;
+    if (a > n) a = n;
+    if (bq < 1) bq = 1;
+    if (bq > n) bq = n;
     return s->action[(a - 1) * n + (bq - 1)];
 }
 
