@@ -61,7 +61,9 @@ struct rbc3_state {
 };
 
 // a contiguous range of envs and the stream its launches go to
-struct rbc3_grp { int e0, B; hipStream_t st; };
+// (Bn: the NOMINAL group size of the handle -- every kernel-choice heuristic reads it instead of B, so that a shorter remainder group runs
+// the same instantiations as the others and an env's result does not depend on which group it sits in)
+struct rbc3_grp { int e0, B; hipStream_t st; int Bn = 0; int nominal() const { return Bn > 0 ? Bn : B; } };
 
 namespace {
 
@@ -461,7 +463,8 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
     auto want = [&](const char *name, bool dflt) { return tshape ? std::strcmp(tshape, name) == 0 : dflt; };
     const bool no_nxc = [] { const char *e = std::getenv("RBC_NO_CONST_GRID"); return e && e[0] == '1'; }();      // A/B: the generic instantiations
     int shape = 0;
-    auto wgs = [&](int ty, int kt) { return 2 * B * (g.ny / ty) * (g.nz / kt); };       // workgroups of one launch
+    const int Bn = q.nominal();
+    auto wgs = [&](int ty, int kt) { return 2 * Bn * (g.ny / ty) * (g.nz / kt); };      // workgroups of one (full-sized) group's launch
     // float32: the tall tiles only once a launch has ~two hundred workgroups.  With four chains in flight a 96-workgroup launch per chain
     // is 384 workgroups on 256 CUs -- a round and a half -- and the half-empty second round costs the float32 kernel (shorter levels,
     // more issue-bound) more than the extra chunk prologues of 16 x 8 tiles: configs[4] float32 9.37k -> 9.94k env-steps/s (+6 %;
@@ -474,7 +477,7 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
     // streaming-2D mode: the same bodies with one-row planes (FLAT), a workgroup = one row of nx threads marching 16 / 8 / 4 levels
     // (tall chunks while the launch keeps a few hundred workgroups; a small batch takes 4 levels: its step is a chain of short kernels)
     if (h->stream2d && !h->no_tile && g.nx <= 256 && g.nz % 4 == 0) {
-        auto enough = [&](int kt) { return g.nz % kt == 0 && 2 * (size_t)B * (g.nz / kt) >= 256; };
+        auto enough = [&](int kt) { return g.nz % kt == 0 && 2 * (size_t)Bn * (g.nz / kt) >= 256; };
         shape = (g.nz >= 64 && enough(32)) ? 8 : (enough(16) ? 5 : (enough(8) ? 6 : 7));     // 32 levels: +1.8 % at 128 x 64 (64: -6 %)
         if (const char *e = std::getenv("RBC_FLAT_KT")) {                                      // A/B knob: 4, 8, 16, 32, 64
             const int kt = std::atoi(e);
@@ -576,17 +579,18 @@ int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, dou
         const int s0 = sl * per_slice, Bs = (s0 + per_slice <= h->B) ? per_slice : h->B - s0;
         if (Bs <= 0) continue;
         if (s->groups <= 1) {
-            const rbc3_grp q{s0, Bs, h->stream};
+            const rbc3_grp q{s0, Bs, h->stream, per_slice};
             if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
             if (with_output) if (int rc = output3d(h, q, which, nullptr)) return rc;
             continue;
         }
         HIP3(hipEventRecord(s->gstart, h->stream));
-        const int per = (Bs + s->groups - 1) / s->groups;
-        for (int gi = 0; gi < s->groups; ++gi) {
-            const int e0 = s0 + gi * per, Bg = (gi * per + per <= Bs) ? per : Bs - gi * per;
+        const int per = (per_slice + s->groups - 1) / s->groups, base = Bs / s->groups, rem = Bs % s->groups;      // balanced: 17 envs = 5 + 4 + 4 + 4
+        for (int gi = 0, e0 = s0; gi < s->groups; ++gi) {
+            const int Bg = base + (gi < rem ? 1 : 0);
             if (Bg <= 0) continue;
-            const rbc3_grp q{e0, Bg, s->gstream[gi]};
+            const rbc3_grp q{e0, Bg, s->gstream[gi], per};
+            e0 += Bg;
             HIP3(hipStreamWaitEvent(q.st, s->gstart, 0));
             if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
             if (with_output) if (int rc = output3d(h, q, which, nullptr)) return rc;

@@ -2,7 +2,9 @@
 
 Every grid the C ABI accepts (2D: >= 8 x 8; 3D: >= 8 cells per direction -- odd and prime sizes included) must give the oracle's answer
 through whichever kernels the host picks for it, for random Rayleigh / Prandtl numbers, domains, plate temperatures, heater counts,
-sensor grids, solver / control steps (ragged last substep) and either clock.  The sweep is seeded, so a failure names its configuration.
+sensor grids, solver / control steps (ragged last substep), either clock, and batch sizes on both sides of the host's thresholds (env
+groups, chain counts, tile shapes: envs beyond the first two or three repeat them and must reproduce them bit for bit).  The sweep is
+seeded, so a failure names its configuration.
 (First run of the sweep, round 4: 260 float64 + 195 float32 draws; the five draws outside the bars were all odd nx and the error was
 the ORACLE's -- tests/test_oracle_golden.py::test_projection_is_exact_on_any_grid_odd_sizes_included.)"""
 import importlib.util
@@ -33,10 +35,12 @@ def test_random_configurations_match_the_oracle(fuzz, precision, seed, n2, n3):
     for n in range(n2):
         cfg, obs, clock = fuzz.draw_2d(rng)
         odd += cfg["nx"] % 2
-        w, wn, wo = fuzz.run_2d(cfg, obs, clock, seed * 1000 + n, precision)
-        assert w < bar_f and wn < bar_nu and wo < bar_obs, (cfg, obs, clock, w, wn, wo)
+        B = fuzz.draw_batch(rng, cfg)
+        w, wn, wo = fuzz.run_2d(cfg, obs, clock, seed * 1000 + n, precision, B)
+        assert w < bar_f and wn < bar_nu and wo < bar_obs, (cfg, obs, clock, B, w, wn, wo)
     for n in range(n3):
         cfg, clock = fuzz.draw_3d(rng)
-        w, wn = fuzz.run_3d(cfg, clock, seed * 1000 + 500 + n, precision)
-        assert w < bar_f and wn < bar_nu, (cfg, clock, w, wn)
+        B = fuzz.draw_batch(rng, cfg)
+        w, wn = fuzz.run_3d(cfg, clock, seed * 1000 + 500 + n, precision, B)
+        assert w < bar_f and wn < bar_nu, (cfg, clock, B, w, wn)
     assert odd >= 1                                                # the draw that found the oracle's even-nx assumption stays in the sweep
