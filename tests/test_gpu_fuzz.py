@@ -44,3 +44,22 @@ def test_random_configurations_match_the_oracle(fuzz, precision, seed, n2, n3):
         w, wn = fuzz.run_3d(cfg, clock, seed * 1000 + 500 + n, precision, B)
         assert w < bar_f and wn < bar_nu, (cfg, clock, B, w, wn)
     assert odd >= 1                                                # the draw that found the oracle's even-nx assumption stays in the sweep
+
+
+@pytest.fixture(scope="module")
+def fuzz_seq():
+    spec = importlib.util.spec_from_file_location("fuzz_sequences", os.path.join(ROOT, "scripts", "fuzz_sequences.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.oracle_py.build_oracle()
+    return mod
+
+
+@pytest.mark.parametrize("target", ["resident-2d", "streaming-2d", "3d"])
+def test_random_call_sequences_match_per_env_oracle_mirrors(fuzz_seq, target):
+    """per-env Rayleigh numbers, then a seeded random walk over step / zero-action step / masked random reset / masked reset from arrays
+    under either clock; after every call every env's fields, Nusselt number, t / step counters against its own oracle instance"""
+    rng = np.random.default_rng({"resident-2d": 41, "streaming-2d": 42, "3d": 43}[target])
+    for q in range(3):
+        worst, log = fuzz_seq.run_sequence(target, rng, 8)
+        assert worst < 1e-9, log
