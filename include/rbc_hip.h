@@ -206,6 +206,10 @@ int  rbc_debug_tendencies(rbc_handle *h, const float *actions, double *gb, doubl
 int  rbc_debug_tendencies3(rbc_handle *h, const float *actions, double *gu, double *gv, double *gw, double *gb);
 /* run `nsub` RK3 substeps of size dt with the given actions (no counters touched)          */
 int  rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt);
+/* how the streaming path (3D, streaming 2D) replays an env-step: groups[0] = env groups (stream chains) of the handle, groups[1] =
+   1 if every group replays its own captured graph on a stream with a hardware queue of its own (found by probing at rbc_create), 0 if
+   the groups are branches of one graph (or launches are direct).  A handle on the LDS-resident 2D kernel reports {1, 0}.          */
+int  rbc_debug_launch_plan(rbc_handle *h, int groups[2]);
 /* diagnostic builds only (-DRBC_STAMPS=1): per-phase shader-clock cycles of the last launch,
    out[B][64]; returns RBC_ERR_INVALID in the shipped build                                 */
 int  rbc_debug_stamps(rbc_handle *h, unsigned long long *out);

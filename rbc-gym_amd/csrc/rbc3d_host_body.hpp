@@ -58,6 +58,14 @@ struct rbc3_state {
     std::vector<hipStream_t> gstream;
     std::vector<hipEvent_t> gdone;
     hipEvent_t gstart = nullptr;
+    // One captured graph PER env group ([parity][length][group]), each a single-stream graph on its group's stream, where the group
+    // streams sit on different hardware queues (own_queues, found out by create3d).  Replaying a single-stream graph costs the
+    // host ~0.1 ms; the one graph over all groups costs ~4 us per node -- 2.3 ms (float64) / 2.8 ms (float32) for configs[4], the
+    // last chain starting 1.5 ms after the first.  Back to back that hides under the previous step; a SYNCHRONOUS caller (gym
+    // semantics: actions in, wait, observations out) pays it on every step: 5.7 -> 4.9 ms float64, 4.7 -> 3.3 ms float32
+    // (scripts/sync_step_latency.py).  RBC_3D_GROUP_GRAPHS=0: the one graph (also the fallback when the queues are shared).
+    std::vector<hipGraphExec_t> ggexec[2][2];
+    bool own_queues = false;
 };
 
 // a contiguous range of envs and the stream its launches go to
@@ -96,6 +104,56 @@ constexpr int RBC_LDS_CEILING = 160 * 1024;
 constexpr int TW3 = std::is_same<real, float>::value ? RBC_F32_TILE_WAVES : 3;
 
 inline rbc3_state *S3(const rbc_handle *h) { return static_cast<rbc3_state *>(h->s3); }
+
+// true if a kernel on `b` can run while one is running on `a`, i.e. the two streams do not share a hardware queue: `a` is held
+// for half a millisecond, an empty kernel goes to `b`; if `a` is already done when `b` has finished, `b` waited behind it.
+int streams_run_side_by_side(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb, bool *yes)
+{
+    hipLaunchKernelGGL(K3C::k3_hold, dim3(1), dim3(64), 0, a, 50000LL);
+    HIP3(hipEventRecord(ea, a));
+    hipLaunchKernelGGL(K3C::k3_hold, dim3(1), dim3(64), 0, b, 0LL);
+    HIP3(hipEventRecord(eb, b));
+    HIP3(hipEventSynchronize(eb));
+    const hipError_t q = hipEventQuery(ea);
+    if (q != hipSuccess && q != hipErrorNotReady) return fail(RBC_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    *yes = (q == hipErrorNotReady);
+    HIP3(hipEventSynchronize(ea));
+    return RBC_OK;
+}
+
+// n streams for the env groups.  The runtime spreads the streams of a process over four hardware queues by a rule of its own
+// (the n-th stream of a fresh process lands on queue 1, 2, 3, 4, 4, 3, 2, 1, 4, 3, ...: scripts/probes/queue_map.hip), so four streams
+// created in a row can sit on two queues -- and two chains on one queue run one after the other (configs[4]: 7.1 ms instead of
+// 4.9).  With `probe`, streams are created one at a time and kept only if they run side by side with every stream already kept (at
+// most 12 tries, ~0.6 ms each); *own_queues says whether that found n of them.  Otherwise the first n are taken as they come.
+int group_streams(rbc_handle *h, int n, bool probe, std::vector<hipStream_t> &out, bool *own_queues)
+{
+    (void)h;
+    out.clear();
+    *own_queues = false;
+    std::vector<hipStream_t> rejected;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (probe) { HIP3(hipEventCreateWithFlags(&ea, hipEventDisableTiming)); HIP3(hipEventCreateWithFlags(&eb, hipEventDisableTiming)); }
+    int rc = RBC_OK;
+    for (int tries = 0; (int)out.size() < n && tries < (probe ? 12 : n) && rc == RBC_OK; ++tries) {
+        hipStream_t c = nullptr;
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) { rc = fail(RBC_ERR_DEVICE, "hipStreamCreateWithFlags failed"); break; }
+        bool keep = true;
+        for (size_t k = 0; probe && keep && k < out.size() && rc == RBC_OK; ++k) rc = streams_run_side_by_side(out[k], c, ea, eb, &keep);
+        (keep ? out : rejected).push_back(c);
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    *own_queues = probe && (int)out.size() == n && rc == RBC_OK;
+    while ((int)out.size() < n && !rejected.empty()) { out.push_back(rejected.back()); rejected.pop_back(); }      // shared queues: still n streams
+    for (hipStream_t c : rejected) (void)hipStreamDestroy(c);
+    while ((int)out.size() < n && rc == RBC_OK) {
+        hipStream_t c = nullptr;
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) rc = fail(RBC_ERR_DEVICE, "hipStreamCreateWithFlags failed");
+        else out.push_back(c);
+    }
+    return rc;
+}
 
 int create3d(rbc_handle *h)
 {
@@ -255,12 +313,11 @@ int create3d(rbc_handle *h)
         if (s->slices > 1 && !std::getenv("RBC_USE_GRAPH")) h->no_graph = false;     // many short launches: replay them as one captured graph
         if (s->groups > 1 && !std::getenv("RBC_USE_GRAPH")) h->no_graph = false;     // several chains: replay them as one captured graph
         if (s->groups > 1) {
-            s->gstream.resize(s->groups); s->gdone.resize(s->groups);
-            for (int q = 0; q < s->groups; ++q) {
-                HIP3(hipStreamCreateWithFlags(&s->gstream[q], hipStreamNonBlocking));
-                HIP3(hipEventCreateWithFlags(&s->gdone[q], hipEventDisableTiming));
-            }
+            s->gdone.resize(s->groups);
+            for (int q = 0; q < s->groups; ++q) HIP3(hipEventCreateWithFlags(&s->gdone[q], hipEventDisableTiming));
             HIP3(hipEventCreateWithFlags(&s->gstart, hipEventDisableTiming));
+            const char *gg = std::getenv("RBC_3D_GROUP_GRAPHS");
+            if (int rc = group_streams(h, s->groups, !h->no_graph && s->slices == 1 && !(gg && gg[0] == '0'), s->gstream, &s->own_queues)) return rc;
         }
     }
     // 3D, mirror-packed path, float64: the inverse FFT marches 2 adjacent slab pairs per workgroup and applies the vertical correction
@@ -298,6 +355,11 @@ void drop_graphs3d(rbc_handle *h)
     for (auto &gp : S3(h)->gexec)
         for (auto &g : gp)
             if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &gp : S3(h)->ggexec)
+        for (auto &gv : gp) {
+            for (hipGraphExec_t g : gv) if (g) (void)hipGraphExecDestroy(g);
+            gv.clear();
+        }
 }
 
 void destroy3d(rbc_handle *h)
@@ -438,12 +500,16 @@ void wall3d(rbc_handle *h, const rbc3_grp &q, const float *actions_dev, int zero
 
 // the stage list of `nsub` substeps (the last of size dt_last) for one group of envs, starting from state buffer `which`;
 // actions already on the device.  Returns the buffer that holds the state afterwards through *which_out.
-int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_dev, int nsub, double dt, double dt_last, int *which_out)
+// (st0, st1: the range of RK3 stages, counted 0 .. 3 nsub - 1 over the whole interval, this call issues -- `which` is the buffer the
+// first of them reads; the default is the whole interval.  run_step3d issues the groups' chains stage by stage, see there.)
+int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_dev, int nsub, double dt, double dt_last, int *which_out,
+              int st0 = 0, int st1 = -1)
 {
     rbc3_state *s = S3(h);
     const K3::Geo3 &g = s->g;
     const int B = q.B;
-    wall3d(h, q, actions_dev, 0);
+    if (st1 < 0) st1 = 3 * nsub;
+    if (st0 == 0) wall3d(h, q, actions_dev, 0);
     const double *gam = s->gam, *zet = s->zet;
     const dim3 gc = grid_for((size_t)B * g.nc, 128), bc(128);
     const size_t eo = (size_t)q.e0 * g.env_stride;
@@ -484,9 +550,9 @@ int advance3d(rbc_handle *h, const rbc3_grp &q, int which, const float *actions_
             if (kt > 0 && g.nz % kt == 0) shape = kt == 64 ? 9 : (kt == 32 ? 8 : (kt == 16 ? 5 : (kt == 8 ? 6 : (kt == 4 ? 7 : shape))));
         }
     }
-    for (int n = 0; n < nsub; ++n) {
+    for (int n = st0 / 3; n < nsub && 3 * n < st1; ++n) {
         const double d = (n == nsub - 1) ? dt_last : dt;
-        for (int ph = 0; ph < 3; ++ph) {
+        for (int ph = (n == st0 / 3) ? st0 % 3 : 0; ph < 3 && 3 * n + ph < st1; ++ph) {
             real *cur = s->st[which] + eo, *nxt = s->st[which ^ 1] + eo;
             const int store_g = (ph != 2);                     // the last stage's tendencies are never read again (zeta^1 = 0)
             if (!shape)                                        // the fallback kernels use the hydrostatic split (pHY' column scan)
@@ -586,15 +652,30 @@ int run_step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, dou
         }
         HIP3(hipEventRecord(s->gstart, h->stream));
         const int per = (per_slice + s->groups - 1) / s->groups, base = Bs / s->groups, rem = Bs % s->groups;      // balanced: 17 envs = 5 + 4 + 4 + 4
+        std::vector<rbc3_grp> qs;
         for (int gi = 0, e0 = s0; gi < s->groups; ++gi) {
             const int Bg = base + (gi < rem ? 1 : 0);
             if (Bg <= 0) continue;
-            const rbc3_grp q{e0, Bg, s->gstream[gi], per};
+            qs.push_back(rbc3_grp{e0, Bg, s->gstream[gi], per});
             e0 += Bg;
-            HIP3(hipStreamWaitEvent(q.st, s->gstart, 0));
-            if (int rc = advance3d(h, q, s->cur, actions_dev, nsub, dt, dt_last, &which)) return rc;
-            if (with_output) if (int rc = output3d(h, q, which, nullptr)) return rc;
-            HIP3(hipEventRecord(s->gdone[gi], q.st));
+            HIP3(hipStreamWaitEvent(s->gstream[gi], s->gstart, 0));
+        }
+        // The chains are issued STAGE BY STAGE across the groups, not chain by chain: a captured graph is replayed in the order
+        // its nodes were recorded (~4 us of host time per node), so chain by chain the last of four chains started 1.5-1.8 ms after
+        // the first -- invisible back to back, a quarter of the step for a synchronous caller (scripts/sync_step_latency.py).
+        static const bool by_chain = [] { const char *v = std::getenv("RBC_3D_ISSUE_ORDER"); return v && v[0] == 'c'; }();
+        const int nst = 3 * nsub, chunk = by_chain ? nst : 1;
+        int w = s->cur;
+        for (int st = 0; st < nst; st += chunk) {
+            int wn = w;
+            for (const rbc3_grp &q : qs)
+                if (int rc = advance3d(h, q, w, actions_dev, nsub, dt, dt_last, &wn, st, st + chunk)) return rc;
+            w = wn;
+        }
+        which = w;
+        for (size_t gi = 0; gi < qs.size(); ++gi) {
+            if (with_output) if (int rc = output3d(h, qs[gi], which, nullptr)) return rc;
+            HIP3(hipEventRecord(s->gdone[gi], qs[gi].st));
             HIP3(hipStreamWaitEvent(h->stream, s->gdone[gi], 0));
         }
     }
@@ -615,7 +696,45 @@ int step3d(rbc_handle *h, const float *actions_dev, int nsub, double dt, double 
         HIP3(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->B * (h->stream2d ? 1 : s->g.heaters) * s->g.heaters * sizeof(float),
                             hipMemcpyDeviceToDevice, h->stream));
     if (rec) HIP3(hipEventRecord(h->ev[2 * h->ev_used], h->stream));
-    if (standard) {
+    if (standard && s->own_queues) {
+        // per-group graphs: captured once per (parity, length) on the groups' own streams, replayed side by side
+        const int par = s->cur, G = s->groups;
+        const int base = h->B / G, rem = h->B % G, per = (h->B + G - 1) / G;
+        std::vector<hipGraphExec_t> &gg = s->ggexec[par][var];
+        if (gg.empty()) {
+            gg.assign((size_t)G, nullptr);
+            int which = par;
+            for (int gi = 0, e0 = 0; gi < G; ++gi) {
+                const int Bg = base + (gi < rem ? 1 : 0);
+                if (Bg <= 0) continue;
+                const rbc3_grp q{e0, Bg, s->gstream[gi], per};
+                e0 += Bg;
+                hipGraph_t graph = nullptr;
+                HIP3(hipStreamBeginCapture(q.st, hipStreamCaptureModeRelaxed));
+                int rc = advance3d(h, q, par, h->d_actions, nsub, dt, dt_last, &which);
+                if (!rc) rc = output3d(h, q, which, nullptr);
+                hipError_t e = hipStreamEndCapture(q.st, &graph);
+                if (rc || e != hipSuccess) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    drop_graphs3d(h);
+                    return rc ? rc : fail(RBC_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                }
+                e = hipGraphInstantiate(&gg[(size_t)gi], graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (e != hipSuccess) { drop_graphs3d(h); return fail(RBC_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+            }
+        }
+        HIP3(hipEventRecord(s->gstart, h->stream));                // the action upload (and whatever the caller ordered before it)
+        for (int gi = 0; gi < G; ++gi) {
+            if (!gg[(size_t)gi]) continue;
+            HIP3(hipStreamWaitEvent(s->gstream[gi], s->gstart, 0));
+            HIP3(hipGraphLaunch(gg[(size_t)gi], s->gstream[gi]));
+            HIP3(hipEventRecord(s->gdone[gi], s->gstream[gi]));
+        }
+        for (int gi = 0; gi < G; ++gi)
+            if (gg[(size_t)gi]) HIP3(hipStreamWaitEvent(h->stream, s->gdone[gi], 0));
+        s->cur = par ^ ((3 * nsub) & 1);
+    } else if (standard) {
         const int par = s->cur;
         if (!s->gexec[par][var]) {
             hipGraph_t graph = nullptr;

@@ -122,6 +122,14 @@ __global__ void __launch_bounds__(256) k3_restore_unmarked(uint32_t *dst, const 
         dst[base + i] = src[base + i];
 }
 
+// Occupies its stream's hardware queue for `ticks` of the 100 MHz wall clock (one wave; bounded by construction).  create3d uses it
+// to find out which of its streams share a hardware queue (host3::streams_run_side_by_side).
+__global__ void __launch_bounds__(64) k3_hold(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // RBCNormalizeObservation fused into the 3D output kernel's float32 state write (the 3D observation IS the state, rbc3D.py:229-232):
 // obs[c] <- maxval * (2 * (obs[c] - min[c]) / (max[c] - min[c]) - 1), optionally clipped -- the same float32 operations in the same
 // order as the numpy expression of rbc_normalize_observation.py:66-74 (no contraction), so results are bit-identical to the host wrapper.

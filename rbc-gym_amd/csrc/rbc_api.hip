@@ -939,6 +939,17 @@ int rbc_debug_stamps(rbc_handle *h, unsigned long long *out)
     return RBC_OK;
 }
 
+int rbc_debug_launch_plan(rbc_handle *h, int groups[2])
+{
+    if (!h || !groups) return fail(RBC_ERR_INVALID, "null argument");
+    groups[0] = 1; groups[1] = 0;
+    if (h->s3) {
+        if (h->s3_f32) { groups[0] = host3f::S3(h)->groups; groups[1] = host3f::S3(h)->own_queues ? 1 : 0; }
+        else { groups[0] = host3::S3(h)->groups; groups[1] = host3::S3(h)->own_queues ? 1 : 0; }
+    }
+    return RBC_OK;
+}
+
 int rbc_debug_substeps(rbc_handle *h, const float *actions, int nsub, double dt)
 {
     if (int rc = check_handle(h)) return rc;

@@ -90,6 +90,7 @@ SYMBOLS = {
     "rbc_debug_tendencies": (C.c_int, [_vp, _fp, _dp, _dp, _dp]),
     "rbc_debug_substeps": (C.c_int, [_vp, _fp, C.c_int, C.c_double]),
     "rbc_debug_stamps": (C.c_int, [_vp, _u64p]),
+    "rbc_debug_launch_plan": (C.c_int, [_vp, _i32p]),
     "rbc_reset_from_arrays3": (C.c_int, [_vp, _u8p, _dp, _dp, _dp, _dp]),
     "rbc_get_fields3": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "rbc_debug_tendencies3": (C.c_int, [_vp, _fp, _dp, _dp, _dp, _dp]),
@@ -342,6 +343,12 @@ class NativeSim:
         self._check(self.lib.rbc_get_info(self.h, _ptr(t, _dp), _ptr(s, _i64p)))
         return t, s
 
+    def launch_plan(self):
+        """(env groups, 1 if every group replays its own graph on a hardware queue of its own) -- include/rbc_hip.h rbc_debug_launch_plan"""
+        g = np.zeros(2, np.int32)
+        self._check(self.lib.rbc_debug_launch_plan(self.h, _ptr(g, _i32p)))
+        return int(g[0]), int(g[1])
+
     def get_flags(self):
         f = np.empty(self.B, np.int32)
         self._check(self.lib.rbc_get_flags(self.h, _ptr(f, _i32p)))
@@ -508,6 +515,12 @@ class NativeSim3D:
         t = np.empty(self.B); s = np.empty(self.B, np.int64)
         self._check(self.lib.rbc_get_info(self.h, _ptr(t, _dp), _ptr(s, _i64p)))
         return t, s
+
+    def launch_plan(self):
+        """(env groups, 1 if every group replays its own graph on a hardware queue of its own) -- include/rbc_hip.h rbc_debug_launch_plan"""
+        g = np.zeros(2, np.int32)
+        self._check(self.lib.rbc_debug_launch_plan(self.h, _ptr(g, _i32p)))
+        return int(g[0]), int(g[1])
 
     def get_flags(self):
         f = np.empty(self.B, np.int32)

@@ -696,3 +696,40 @@ def test_3d_env_groups_on_the_legacy_default_stream(native):
         assert np.array_equal(ref.get_state(), got)
     sim._check(sim.lib.rbc_set_stream(sim.h, None))
     sim.close(); ref.close()
+
+
+def test_env_groups_replay_their_own_graphs_on_their_own_hardware_queues(native):
+    """The runtime spreads a process's streams over four hardware queues by a rule of its own (scripts/probes/queue_map.hip): four
+    streams created in a row can land on two queues, and two chains on one queue run one after the other.  rbc_create probes
+    (include/rbc_hip.h rbc_debug_launch_plan) -- also with other streams and other handles alive in the process, which shift the
+    rule's phase -- and the per-group graphs give bit for bit the state of the one graph over all groups (RBC_3D_GROUP_GRAPHS=0)."""
+    import torch
+    extra = [torch.cuda.Stream() for _ in range(3)]                 # somebody else's streams, created first
+    kw = dict(batch=16, shape=(16, 32, 32), ra=5000.0, dt_control=0.05, dt_solver=0.01, random_kick=0.2)
+    sims = [native.NativeSim3D(**kw) for _ in range(3)]             # three live handles: 12 group streams on 4 queues
+    for sim in sims:
+        assert sim.launch_plan() == (4, 1)
+    small = native.NativeSim3D(batch=3, shape=(16, 32, 32))
+    assert small.launch_plan() == (1, 0)                            # one group: the handle's stream, direct launches
+    small.close()
+    act = np.random.default_rng(8).uniform(-1, 1, (3, 16, 8, 8)).astype(np.float32)
+    os.environ["RBC_3D_GROUP_GRAPHS"] = "0"
+    try:
+        ref = native.NativeSim3D(**kw)
+    finally:
+        del os.environ["RBC_3D_GROUP_GRAPHS"]
+    assert ref.launch_plan() == (4, 0)
+    seeds = np.arange(16, dtype=np.uint64) + 9
+    for sim in sims + [ref]:
+        sim.reset(seeds)
+    for n in range(3):                                              # the handles step alternately: both parities of every graph
+        for sim in sims + [ref]:
+            assert sim.step(act[n])
+    want = ref.get_fields()
+    for sim in sims:
+        for x, y in zip(sim.get_fields(), want):
+            assert np.array_equal(x, y)
+        assert np.array_equal(sim.get_nusselt(), ref.get_nusselt()) and np.array_equal(sim.get_state(), ref.get_state())
+    for sim in sims + [ref]:
+        sim.close()
+    del extra
