@@ -277,11 +277,11 @@ def gym_api_rate(ctx, B, steps, info_state):
     venv = RayleighBenardConvection2DVectorEnv(num_envs=B, device=ctx["local_rank"], info_state=info_state, episode_length=10**9)
     venv.reset(seed=1234)
     rng = np.random.default_rng(5)
-    acts = rng.uniform(-1, 1, (steps + 1, B, 12)).astype(np.float32)
-    venv.step(acts[0])
+    acts = rng.uniform(-1, 1, (steps + 2, B, 12)).astype(np.float32)
+    venv.step(acts[0]); venv.step(acts[1])
     t0 = time.perf_counter()
     for n in range(steps):
-        venv.step(acts[n + 1])
+        venv.step(acts[n + 2])
     dt = time.perf_counter() - t0
     venv.close()
     return B * steps / dt
@@ -353,11 +353,11 @@ def gym_api_rate_3d(ctx, B, steps, obs_buffers, precision="f64"):
     venv = RayleighBenardConvection3DVectorEnv(num_envs=B, state_shape=(32, 48, 48), rayleigh_number=1e4, device=ctx["local_rank"],
                                                episode_length=10**9, obs_buffers=obs_buffers, precision=precision)
     venv.reset(seed=1234)
-    acts = np.random.default_rng(5).uniform(-1, 1, (steps + 1, B, 8, 8)).astype(np.float32)
-    venv.step(acts[0])
+    acts = np.random.default_rng(5).uniform(-1, 1, (steps + 2, B, 8, 8)).astype(np.float32)
+    venv.step(acts[0]); venv.step(acts[1])                           # both ping-pong parities of the captured graphs
     t0 = time.perf_counter()
     for n in range(steps):
-        venv.step(acts[n + 1])
+        venv.step(acts[n + 2])
     dt = time.perf_counter() - t0
     venv.close()
     return B * steps / dt
@@ -550,15 +550,19 @@ def main():
                 extra["copy_ceiling"] = _native.copy_ceiling(local_rank)
                 out["roofline"]["on_box_copy_gbs"] = extra["copy_ceiling"]["kernel_gbs"]
                 extra["gym_api_env_steps_per_s"] = {
-                    "no_info_state": gym_api_rate(ctx, B, 5, False), "pinned_info_state": gym_api_rate(ctx, B, 5, "pinned"),
-                    "note": "B x VectorEnv.step() per wall second, host actions in, host obs/reward/info out; 5 steps after 1 warm-up"}
+                    "no_info_state": gym_api_rate(ctx, B, 5, False), "default_info_state": gym_api_rate(ctx, B, 5, True),
+                    "always_new_arrays": gym_api_rate(ctx, B, 5, "fresh"),
+                    "note": "B x VectorEnv.step() per wall second, host actions in, host obs/reward/info out; 5 steps after 2 warm-up steps. "
+                            "default_info_state: info['state'] (75 MB of float32 per step) in pooled page-locked arrays that are reused once the "
+                            "caller has dropped them; always_new_arrays: np.empty every step"}
                 d3 = run_3d(ctx, 32, 40, 5, 1e4)
                 extra["config4_3d"] = {k: d3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                           "nan_envs", "mean_nusselt")}
                 extra["gym_api_3d_env_steps_per_s"] = {
-                    "fresh_arrays": gym_api_rate_3d(ctx, 32, 8, None), "pinned_buffers": gym_api_rate_3d(ctx, 32, 8, "pinned"),
-                    "pinned_buffers_fp32": gym_api_rate_3d(ctx, 32, 8, "pinned", "f32") if _native.has_precision("f32") else None,
-                    "note": "configs[4], B x VectorEnv.step() per wall second with the 38 MB of float32 observations crossing PCIe every step; 8 steps after 1 warm-up"}
+                    "default": gym_api_rate_3d(ctx, 32, 8, None), "always_new_arrays": gym_api_rate_3d(ctx, 32, 8, "fresh"),
+                    "default_fp32": gym_api_rate_3d(ctx, 32, 8, None, "f32") if _native.has_precision("f32") else None,
+                    "note": "configs[4], B x VectorEnv.step() per wall second with the 38 MB of float32 observations crossing PCIe every step; "
+                            "8 steps after 2 warm-up steps. default: pooled page-locked observation arrays, reused once the caller has dropped them"}
                 if _native.has_precision("f32"):           # the float32 instantiation of the same 3D kernels (153 MB algorithmic per env-step)
                     d3f = run_3d(ctx, 32, 40, 5, 1e4, "f32")
                     extra["config4_3d_fp32"] = {k: d3f[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 // -DRBC_EXPERIMENTS=1: A/B builds made by scripts/ that read the numerics- or launch-shape-changing RBC_EXPERIMENT_* environment
@@ -68,6 +69,9 @@ struct rbc_handle {
     std::vector<uint8_t> inited;
     std::vector<double> stage;        // host staging for reset_from_arrays
     std::vector<uint8_t> fresh;       // RBC_CLOCK_RECORDED: envs whose next env-step is the first after their reset (staging of d_mask)
+    void *out_stage = nullptr;         // page-locked staging of large float32 outputs bound for pageable caller memory (copy_channels)
+    size_t out_stage_cap = 0;
+    std::vector<hipEvent_t> out_ev;    // one per staged chunk
     std::vector<hipEvent_t> ev;       // profiling: (start, stop) pairs, one pair per timed launch
     size_t ev_used = 0;               // pairs recorded since the last rbc_profile_read
     bool profiling = false;
@@ -392,6 +396,8 @@ int rbc_destroy(rbc_handle *h)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->out_ev) (void)hipEventDestroy(e);
+    if (h->out_stage) (void)hipHostFree(h->out_stage);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return RBC_OK;
@@ -626,8 +632,61 @@ static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t cha
     if (nch < 1 || nch > total) return fail(RBC_ERR_INVALID, "nch out of range");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy2D(out, (size_t)nch * chan * sizeof(float), dev, total * chan * sizeof(float),
-                        (size_t)nch * chan * sizeof(float), h->B, hipMemcpyDeviceToHost));
+    const size_t row = (size_t)nch * chan * sizeof(float), bytes = row * h->B;
+    // Large outputs into PAGEABLE caller memory -- the fresh numpy array of every step that the reference's API returns (rbc2D.py:185-196):
+    // 75 MB of float32 states at B = 1024 in 2D, 38 MB of observations at configs[4] in 3D.  hipMemcpy stages such a copy through
+    // its own bounce buffers at ~11 GB/s, most of it the first touch of freshly mapped pages by one thread.  Here the block crosses
+    // PCIe in chunks into a page-locked buffer of the handle (~50 GB/s) and a few threads move each chunk on as it lands, touching
+    // the destination's pages in parallel.  Page-locked destinations (rbc_host_alloc, obs_buffers="pinned") keep the direct copy.
+    static const bool staged_off = [] { const char *e = std::getenv("RBC_STAGED_COPY"); return e && e[0] == '0'; }();
+    bool pageable = false;
+    if (bytes >= ((size_t)8 << 20) && !staged_off) {
+        hipPointerAttribute_t at;
+        const hipError_t e = hipPointerGetAttributes(&at, out);
+        if (e != hipSuccess) { (void)hipGetLastError(); pageable = true; }          // not known to the runtime: ordinary host memory
+        else pageable = (at.type == hipMemoryTypeUnregistered);
+    }
+    if (!pageable) {
+        HIP_TRY(hipMemcpy2D(out, row, dev, total * chan * sizeof(float), row, h->B, hipMemcpyDeviceToHost));
+        return RBC_OK;
+    }
+    if (h->out_stage_cap < bytes) {
+        if (h->out_stage) { (void)hipHostFree(h->out_stage); h->out_stage = nullptr; h->out_stage_cap = 0; }
+        HIP_TRY(hipHostMalloc(&h->out_stage, bytes, hipHostMallocDefault));
+        h->out_stage_cap = bytes;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int T = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1), K = 2 * T;
+    while ((int)h->out_ev.size() < K) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->out_ev.push_back(ev);
+    }
+    const int per = (h->B + K - 1) / K;
+    char *stage = static_cast<char *>(h->out_stage);
+    int chunks = 0;
+    for (int c = 0; c < K && c * per < h->B; ++c, ++chunks) {
+        const int r0 = c * per, nr = (r0 + per <= h->B) ? per : h->B - r0;
+        HIP_TRY(hipMemcpy2DAsync(stage + (size_t)r0 * row, row, dev + (size_t)r0 * total * chan, total * chan * sizeof(float), row, nr,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->out_ev[c], h->stream));
+    }
+    std::vector<hipError_t> res((size_t)T, hipSuccess);
+    auto mover = [&](int t) {
+        (void)hipSetDevice(h->cfg.device);
+        for (int c = t; c < chunks; c += T) {
+            const hipError_t e = hipEventSynchronize(h->out_ev[c]);
+            if (e != hipSuccess) { res[(size_t)t] = e; return; }
+            const int r0 = c * per, nr = (r0 + per <= h->B) ? per : h->B - r0;
+            std::memcpy(reinterpret_cast<char *>(out) + (size_t)r0 * row, stage + (size_t)r0 * row, (size_t)nr * row);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(mover, t);
+    mover(0);
+    for (auto &x : th) x.join();
+    for (hipError_t e : res)
+        if (e != hipSuccess) return fail(RBC_ERR_DEVICE, std::string("staged copy: ") + hipGetErrorString(e));
     return RBC_OK;
 }
 

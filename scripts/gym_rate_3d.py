@@ -1,10 +1,10 @@
 """gym-API rate of the 3D vector env at configs[4]: B x VectorEnv.step() per wall second, host actions in, host observations (the
-float32 states, 38 MB per step) out; fresh arrays against rotating page-locked buffers, both precisions."""
+float32 states, 38 MB per step) out; always-new arrays ("fresh") against the default (pooled page-locked arrays, reused once dropped) and unconditionally rotating page-locked buffers ("pinned"), both precisions."""
 import sys, time, numpy as np
 sys.path.insert(0, "rbc-gym_amd")
 import rbc_gym
 from rbc_gym._gym import gym
-for prec, bufs in (("f64", None), ("f64", "pinned"), ("f32", None), ("f32", "pinned")):
+for prec, bufs in (("f64", "fresh"), ("f64", None), ("f64", "pinned"), ("f32", "fresh"), ("f32", None), ("f32", "pinned")):
     venv = gym.make_vec("rbc_gym/RayleighBenardConvection3D-v0", num_envs=32, state_shape=(32, 48, 48), rayleigh_number=10000, episode_length=10**9, precision=prec, obs_buffers=bufs)
     venv.reset(seed=1)
     acts = np.random.default_rng(0).uniform(-1, 1, (12, 32, 8, 8)).astype(np.float32)

@@ -9,7 +9,7 @@ import rbc_gym  # noqa
 from rbc_gym._gym import gym
 
 B = 1024
-for info_state in (False, True, "pinned"):
+for info_state in (False, "fresh", True, "pinned"):
     env = gym.make_vec("rbc_gym/RayleighBenardConvection2D-v0", num_envs=B, info_state=info_state)
     env.reset(seed=0)
     a = np.random.default_rng(0).uniform(-1, 1, (B, 12)).astype(np.float32)

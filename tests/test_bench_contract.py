@@ -115,7 +115,7 @@ def test_extra_keys_are_measured_in_the_same_run():
     x = d["extra"]
     assert "error" not in x, x
     assert x["copy_ceiling"]["kernel_gbs"] > 500 and x["copy_ceiling"]["memcpy_d2d_gbs"] > 500
-    assert x["gym_api_env_steps_per_s"]["no_info_state"] > 0 and x["gym_api_env_steps_per_s"]["pinned_info_state"] > 0
+    assert x["gym_api_env_steps_per_s"]["no_info_state"] > 0 and x["gym_api_env_steps_per_s"]["default_info_state"] > 0 and x["gym_api_env_steps_per_s"]["always_new_arrays"] > 0
     c4 = x["config4_3d"]
     assert c4["nan_envs"] == 0 and c4["value"] > 0 and "32x48x48" in c4["config"]["workload"]
     assert d["roofline"]["on_box_copy_gbs"] == x["copy_ceiling"]["kernel_gbs"]

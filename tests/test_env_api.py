@@ -104,3 +104,42 @@ def test_reference_clock_kwarg_is_validated_before_any_device_call():
                  lambda: RayleighBenardConvection3DVectorEnv(num_envs=2, reference_clock="julia")):
         with pytest.raises(ValueError, match="reference_clock"):
             make()
+
+
+def test_output_pool_never_hands_out_an_array_the_caller_still_holds(monkeypatch):
+    """_native.PinnedPool: large outputs come from page-locked arrays that are reused only when nothing but the pool references
+    them -- the caller's own name, a view, a dict entry or a list slot all keep an array out of circulation, so what the env returned
+    is never written again while it can still be read (the reference returns a new array from every step: rbc2D.py:185-196)."""
+    from rbc_gym import _native
+    made = []
+
+    def fake_pinned(shape, dtype=np.float32):            # no GPU here: ordinary memory, same bookkeeping
+        made.append(1)
+        return np.empty(shape, dtype)
+    monkeypatch.setattr(_native, "pinned_empty", fake_pinned)
+    pool = _native.PinnedPool((4, 3), cap=3)
+    a = pool.take()
+    ida = id(a)
+    b = pool.take()
+    assert b is not a                                    # `a` is still held
+    del a
+    c = pool.take()
+    assert id(c) == ida and len(made) == 2               # dropped: back in circulation, nothing new allocated
+    view = c[1]                                          # a view keeps its base alive -- and out of the pool
+    del c
+    d = pool.take()
+    assert id(d) != ida and d is not b and len(made) == 3
+    info = {"state": d}
+    del d
+    assert pool.take() is None                           # b, the view's base and the dict's array: all three are held
+    del info
+    e = pool.take()
+    assert e is not None and e is not b and len(made) == 3
+    del view, b, e
+    assert id(pool.take()) in {id(x) for x in pool._items}
+
+    def no_memory(shape, dtype=np.float32):
+        raise MemoryError
+    monkeypatch.setattr(_native, "pinned_empty", no_memory)
+    empty = _native.PinnedPool((2, 2))
+    assert empty.take() is None and empty.cap == 0       # no page-locked memory: the getter falls back to an ordinary array

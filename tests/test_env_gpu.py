@@ -844,3 +844,44 @@ def test_sharded_3d_env_with_env_groups_and_graphs(gym):
         oa, ra, *_ = a.step(act); ob, rb, *_ = b.step(act)
         assert np.array_equal(oa, ob) and np.array_equal(ra, rb), n
     a.close(); b.close()
+
+
+def test_large_outputs_come_from_a_pool_but_a_held_array_is_never_rewritten(gym):
+    """default obs_buffers / info_state: every step returns an array that is the caller's for as long as it is held (the reference's
+    contract), yet in a loop that drops them the same two page-locked arrays go round (rbc_gym._native.PinnedPool) -- bitwise the
+    values of the always-np.empty mode ("fresh")"""
+    import rbc_gym  # noqa: F401
+    from rbc_gym.vector import RayleighBenardConvection2DVectorEnv, RayleighBenardConvection3DVectorEnv
+    kw3 = dict(num_envs=16, state_shape=(32, 48, 48), rayleigh_number=10000, episode_length=10 ** 6)        # 18.9 MB of observations
+    pooled, fresh = RayleighBenardConvection3DVectorEnv(**kw3), RayleighBenardConvection3DVectorEnv(obs_buffers="fresh", **kw3)
+    rng = np.random.default_rng(0)
+    o0, _ = pooled.reset(seed=5); f0, _ = fresh.reset(seed=5)
+    assert np.array_equal(o0, f0)
+    held, copies, seen = [o0], [o0.copy()], {id(o0)}
+    for n in range(6):
+        a = rng.uniform(-1, 1, (16, 8, 8)).astype(np.float32)
+        o = pooled.step(a)[0]; f = fresh.step(a)[0]
+        assert np.array_equal(o, f)
+        if n < 2:                                                    # keep the first three arrays for ever ...
+            held.append(o); copies.append(o.copy())
+        seen.add(id(o))
+        del o
+    for h, c in zip(held, copies):                                   # ... nothing has written to them since
+        assert np.array_equal(h, c)
+    assert len(seen) <= 5                                            # three held + the one or two that go round; 7 with fresh arrays
+    pooled.close(); fresh.close()
+    kw2 = dict(num_envs=128, episode_length=10 ** 6)                 # info["state"]: 9.4 MB
+    pooled, fresh = RayleighBenardConvection2DVectorEnv(**kw2), RayleighBenardConvection2DVectorEnv(info_state="fresh", **kw2)
+    pooled.reset(seed=5); fresh.reset(seed=5)
+    first = None
+    ids = set()
+    for n in range(5):
+        a = rng.uniform(-1, 1, (128, 12)).astype(np.float32)
+        ip = pooled.step(a)[4]; jf = fresh.step(a)[4]
+        assert np.array_equal(ip["state"], jf["state"])
+        if first is None:
+            first = (ip["state"], ip["state"].copy())
+        ids.add(id(ip["state"]))
+        del ip
+    assert np.array_equal(*first) and len(ids) <= 3
+    pooled.close(); fresh.close()
