@@ -682,8 +682,12 @@ static int copy_channels(rbc_handle *h, float *out, const float *dev, size_t cha
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(mover, t);
+    int started = 1;                                     // mover 0 is this thread
+    try {
+        for (int t = 1; t < T; ++t) { th.emplace_back(mover, t); ++started; }
+    } catch (...) { /* no more threads to be had: this thread moves their chunks too (nothing may be thrown across the C ABI) */ }
     mover(0);
+    for (int t = started; t < T; ++t) mover(t);
     for (auto &x : th) x.join();
     for (hipError_t e : res)
         if (e != hipSuccess) return fail(RBC_ERR_DEVICE, std::string("staged copy: ") + hipGetErrorString(e));
