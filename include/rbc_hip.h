@@ -136,9 +136,10 @@ int   rbc_get_cell_distances(rbc_handle *h, double height, double *out);
 void *rbc_dev_cell_dist(rbc_handle *h);
 int   rbc_debug_cell_distances(int device, const float *uy, int B, int nx, double lx, double height, double *out);
 
-/* Page-locked host buffers for the rbc_get_* outputs: a pageable destination limits the float32 state copy of 1024
-   envs (75 MB) to the driver's staging rate, a pinned one takes it at PCIe speed.  Plain helpers over hipHostMalloc /
-   hipHostFree; any rbc_get_* accepts either kind of pointer.                                                        */
+/* Page-locked host buffers for the rbc_get_* outputs: a pinned destination takes the float32 state copy of 1024 envs (75 MB)
+   at PCIe speed.  Plain helpers over hipHostMalloc / hipHostFree; any rbc_get_* accepts either kind of pointer.  Into PAGEABLE
+   memory, rbc_get_obs / rbc_get_state outputs of 8 MiB and more are staged in chunks through a page-locked buffer of the handle
+   and moved on by up to four host threads while the next chunk is in flight (RBC_STAGED_COPY=0: one hipMemcpy2D).      */
 void *rbc_host_alloc(size_t bytes);
 void  rbc_host_free(void *p);
 
