@@ -363,6 +363,24 @@ def gym_api_rate_3d(ctx, B, steps, obs_buffers, precision="f64"):
     return B * steps / dt
 
 
+def sync_step_ms_3d(ctx, B, steps, precision="f64"):
+    """configs[4], one SYNCHRONOUS rbc_step (host actions in, wait, NaN flags back): what a gym-style caller pays per step of B envs,
+    against `ms_per_step` of the back-to-back device-resident run (launch plan)"""
+    np = ctx["np"]
+    from rbc_gym import _native
+    sim = _native.NativeSim3D(batch=B, device=ctx["local_rank"], shape=(32, 48, 48), ra=1e4, dt_control=0.125, dt_solver=0.01, precision=precision)
+    sim.reset(np.arange(B, dtype=np.uint64) + 1234)
+    acts = np.random.default_rng(5).uniform(-1, 1, (steps + 2, B, 8, 8)).astype(np.float32)
+    sim.step(acts[0]); sim.step(acts[1])
+    t0 = time.perf_counter()
+    for n in range(steps):
+        sim.step(acts[n + 2])
+    dt = (time.perf_counter() - t0) / steps
+    plan = sim.launch_plan()
+    sim.close()
+    return {"ms": dt * 1e3, "env_groups": plan[0], "own_graph_and_hardware_queue_per_group": bool(plan[1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -561,6 +579,7 @@ def main():
                 extra["gym_api_3d_env_steps_per_s"] = {
                     "default": gym_api_rate_3d(ctx, 32, 8, None), "always_new_arrays": gym_api_rate_3d(ctx, 32, 8, "fresh"),
                     "default_fp32": gym_api_rate_3d(ctx, 32, 8, None, "f32") if _native.has_precision("f32") else None,
+                    "sync_step": {"f64": sync_step_ms_3d(ctx, 32, 10), "f32": sync_step_ms_3d(ctx, 32, 10, "f32") if _native.has_precision("f32") else None},
                     "note": "configs[4], B x VectorEnv.step() per wall second with the 38 MB of float32 observations crossing PCIe every step; "
                             "8 steps after 2 warm-up steps. default: pooled page-locked observation arrays, reused once the caller has dropped them"}
                 if _native.has_precision("f32"):           # the float32 instantiation of the same 3D kernels (153 MB algorithmic per env-step)
