@@ -1515,6 +1515,7 @@ dbl2 *pk = park(1);
     }
 }
 
+#ifndef RBC2D_TEMPLATE_ONLY      /* the two small non-template kernels below belong to rbc_api.hip's translation unit only */
 // RBCRewardShaping.compute_cell_distances (wrappers/rbc_reward_shaping.py:85-140) for a batch of mid-line signals, one
 // wave64 per env: uy[env * stride + i], i < nx <= 256 (the float32 w channel of the state at row nz/2 - 1).
 //   peaks = scipy.signal.find_peaks(uy, height): strict rise before, strict fall after, a flat top counts once at its
@@ -1587,5 +1588,6 @@ __global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ s
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
+#endif   /* RBC2D_TEMPLATE_ONLY */
 
 }  // namespace rbc

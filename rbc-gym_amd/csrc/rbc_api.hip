@@ -5,9 +5,20 @@
 // file only owns device buffers, the per-env clocks (api:12-13,67-68,87-88) and the launches.
 // There is deliberately no CPU fallback: every entry point that needs the GPU fails with
 // RBC_ERR_DEVICE when HIP does.
-#include "rbc2d_kernel.hpp"
+#include "rbc2d_instances.hpp"
 
 #include "../../include/rbc_hip.h"
+
+// the resident 2D kernels are defined in rbc2d_instances.hip (own translation unit, own scheduling strategy)
+#define RBC2D_DECLARE(NX, NZ, T)                                                                    \
+    extern template __global__ void rbc::rbc2d_kernel<NX, NZ, T, false>(const rbc::Params2D); \
+    extern template __global__ void rbc::rbc2d_kernel<NX, NZ, T, true>(const rbc::Params2D);
+#define RBC2D_DECLARE_PROD(NX, NZ, T) extern template __global__ void rbc::rbc2d_kernel<NX, NZ, T, false>(const rbc::Params2D);
+RBC2D_INSTANCES_F64(RBC2D_DECLARE)
+RBC2D_INSTANCES_F32(RBC2D_DECLARE)
+RBC2D_INSTANCES_F32X2(RBC2D_DECLARE_PROD)
+#undef RBC2D_DECLARE
+#undef RBC2D_DECLARE_PROD
 
 #include <cmath>
 #include <cstdio>
@@ -109,15 +120,13 @@ bool bind_grid(rbc_handle *h, int nx, int nz, int precision)
 {
 #define RBC_GRID(NX_, NZ_, T_) if (nx == NX_ && nz == NZ_) { bind_kernel<NX_, NZ_, T_>(h); return true; }
     if (precision == RBC_PRECISION_F64) {
-        RBC_GRID(96, 64, double) RBC_GRID(96, 48, double) RBC_GRID(96, 32, double)
-        RBC_GRID(64, 64, double) RBC_GRID(64, 48, double) RBC_GRID(64, 32, double)
-        RBC_GRID(128, 32, double)
+        RBC2D_INSTANCES_F64(RBC_GRID)
     } else if (precision == RBC_PRECISION_F32) {
         // packed pairs (two envs per workgroup, v_pk_*_f32: the f64 kernel's instruction stream at two envs per instruction)
         // where a pair fits the LDS; RBC_F32_SCALAR=1 selects the one-env-per-workgroup float kernel instead (A/B reference)
         const char *e = std::getenv("RBC_F32_SCALAR");
-        if (!(e && e[0] == '1')) { RBC_GRID(96, 64, rbc::f32x2) RBC_GRID(64, 64, rbc::f32x2) }
-        RBC_GRID(96, 64, float) RBC_GRID(128, 64, float) RBC_GRID(64, 64, float) RBC_GRID(192, 32, float)
+        if (!(e && e[0] == '1')) { RBC2D_INSTANCES_F32X2(RBC_GRID) }
+        RBC2D_INSTANCES_F32(RBC_GRID)
     }
 #undef RBC_GRID
     return false;

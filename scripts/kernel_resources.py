@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Register / scratch / LDS budget of every kernel in librbc_hip.so, read from the gfx950 code object's metadata.
+"""Register / scratch / LDS budget of every kernel in librbc_hip.so, read from the metadata of its gfx950 code objects (one per translation unit).
 
     python scripts/kernel_resources.py [path/to/librbc_hip.so] [substring ...]
 
@@ -37,11 +37,18 @@ def kernel_resources(lib=None):
     """-> {demangled kernel name: {key: int}} for the gfx950 code object inside `lib`."""
     lib = lib or os.path.join(ROOT, "rbc-gym_amd", "lib", "librbc_hip.so")
     with tempfile.TemporaryDirectory() as tmp:
-        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
+        fat = os.path.join(tmp, "fat.bin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", lib])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
-                               f"--targets={TARGET}", f"--output={co}"])
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+        # one offload bundle per translation unit of the library (rbc2d_instances.hip, rbc_api.hip), back to back in the section
+        blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        notes = ""
+        for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+            part, co = os.path.join(tmp, f"fat{n}.bin"), os.path.join(tmp, f"k{n}.co")
+            open(part, "wb").write(blob[a:b])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                                   f"--targets={TARGET}", f"--output={co}"])
+            notes += subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout + "\n"
     kernels, cur = [], None
     for line in notes.splitlines():
         m = re.match(r"\s*(- )?\.(\w+):\s*(.*)$", line)
