@@ -15,9 +15,9 @@ NAMES = ["setup+outputs", "prepass barrier wait", "u tend", "b tend", "stash+w t
 
 
 def build():
-    src = os.path.join(ROOT, "rbc-gym_amd", "csrc", "rbc_api.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-Wno-unused-value", "-DRBC_STAMPS=1", "-o", SO, src])
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge                           # the library's own two-unit build, with the stamp hooks compiled in
+    ge.build_hip(force=True, extra_flags=("-DRBC_STAMPS=1",), out=SO)
 
 
 if __name__ == "__main__":

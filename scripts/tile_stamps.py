@@ -16,9 +16,9 @@ NAMES = ["shift windows + issue next level's loads", "first field (u | w)", "sec
 
 if __name__ == "__main__":
     if "--build" in sys.argv:
-        src = os.path.join(ROOT, "rbc-gym_amd", "csrc", "rbc_api.hip")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-Wno-unused-value", "-DRBC_STAMPS=1", "-o", SO, src])
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge                       # the library's own two-unit build, with the stamp hooks compiled in
+        ge.build_hip(force=True, extra_flags=("-DRBC_STAMPS=1",), out=SO)
         sys.exit(0)
     os.environ["RBC_HIP_LIB"] = SO
     os.environ.setdefault("RBC_3D_GROUPS", "1")
